@@ -1,0 +1,370 @@
+// mr_api.cpp -- the extern "C" boundary declared in include/miro_hip.h.
+// Scene assembly and BVH::build run on the host; mr_bvh_build flattens the tree into the device
+// layout of mr_internal.h and uploads it once; mr_trace only moves rays/hits and launches.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "mr_internal.h"
+
+namespace mr {
+
+static thread_local char g_err[512] = "";
+
+mr_status fail(mr_status code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+namespace {
+
+template <typename T>
+mr_status upload(T *&dst, const T *src, size_t count, uint64_t &bytes) {
+    const size_t sz = (count ? count : 1) * sizeof(T);
+    MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&dst), sz));
+    if (count) MR_HIP_CHECK(hipMemcpy(dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    bytes += sz;
+    return MR_OK;
+}
+
+void release_device(mr_scene *s) {
+    DeviceScene &d = s->dev;
+    (void)hipFree(d.nodes); (void)hipFree(d.tris); (void)hipFree(d.tri_prim); (void)hipFree(d.leaf_cnt_ext);
+    (void)hipFree(d.v); (void)hipFree(d.n); (void)hipFree(d.vi); (void)hipFree(d.ni);
+    d = DeviceScene();
+    (void)hipFree(s->d_stats); s->d_stats = nullptr;
+    (void)hipFree(s->d_stage_rays); (void)hipFree(s->d_stage_hits);
+    s->d_stage_rays = s->d_stage_hits = nullptr;
+    s->stage_cap = 0;
+}
+
+inline int32_t leaf_ref(uint32_t first, uint32_t count) {
+    const uint32_t c = count < (uint32_t)kLeafCountMask ? count : (uint32_t)kLeafCountMask;
+    return (int32_t)~((first << kLeafCountBits) | c);
+}
+
+// host tree -> device records
+mr_status flatten_and_upload(mr_scene *s) {
+    const HostTree &t = s->tree;
+    const HostMesh &m = s->mesh;
+    DeviceScene &d = s->dev;
+    const uint32_t nt = m.n_triangles();
+    if (nt >= (1u << (31 - kLeafCountBits)))
+        return fail(MR_ERR_INVALID, "scene has %u triangles; the leaf reference encoding holds < %u", nt,
+                    1u << (31 - kLeafCountBits));
+
+    // inner nodes get consecutive ids in DFS order
+    std::vector<int32_t> inner_id(t.nodes.size(), -1);
+    uint32_t n_inner = 0;
+    for (size_t i = 0; i < t.nodes.size(); i++)
+        if (!t.nodes[i].is_leaf) inner_id[i] = (int32_t)n_inner++;
+    auto ref_of = [&](int32_t node) -> int32_t {
+        const HostNode &nd = t.nodes[(size_t)node];
+        return nd.is_leaf ? leaf_ref((uint32_t)nd.a, (uint32_t)nd.b) : inner_id[(size_t)node];
+    };
+
+    std::vector<float4> nodes((size_t)n_inner * 4);
+    for (size_t i = 0; i < t.nodes.size(); i++) {
+        const HostNode &nd = t.nodes[i];
+        if (nd.is_leaf) continue;
+        const HostNode &c0 = t.nodes[(size_t)nd.a], &c1 = t.nodes[(size_t)nd.b];
+        float4 *q = &nodes[(size_t)inner_id[i] * 4];
+        q[0] = make_float4(c0.lo[0], c0.hi[0], c0.lo[1], c0.hi[1]);
+        q[1] = make_float4(c1.lo[0], c1.hi[0], c1.lo[1], c1.hi[1]);
+        q[2] = make_float4(c0.lo[2], c0.hi[2], c1.lo[2], c1.hi[2]);
+        int32_t refs[4] = {ref_of(nd.a), ref_of(nd.b), 0, 0};
+        memcpy(&q[3], refs, sizeof(refs));
+    }
+
+    // triangles pre-gathered in leaf order: A, B-A, C-A, (B-A)x(C-A)  (Triangle.cpp:143-151)
+    std::vector<float4> tris((size_t)nt * 3);
+    std::vector<uint32_t> cnt_ext(nt, 0);
+    for (uint32_t k = 0; k < nt; k++) {
+        const uint32_t prim = t.leaf_prims[k];
+        const float *A = &m.v[3 * (size_t)m.vi[3 * prim]];
+        const float *B = &m.v[3 * (size_t)m.vi[3 * prim + 1]];
+        const float *C = &m.v[3 * (size_t)m.vi[3 * prim + 2]];
+        const float bx = B[0] - A[0], by = B[1] - A[1], bz = B[2] - A[2];
+        const float cx = C[0] - A[0], cy = C[1] - A[1], cz = C[2] - A[2];
+        const float nx = by * cz - bz * cy, ny = bz * cx - bx * cz, nz = bx * cy - by * cx;
+        tris[3 * (size_t)k + 0] = make_float4(A[0], A[1], A[2], bx);
+        tris[3 * (size_t)k + 1] = make_float4(by, bz, cx, cy);
+        tris[3 * (size_t)k + 2] = make_float4(cz, nx, ny, nz);
+    }
+    for (const HostNode &nd : t.nodes)
+        if (nd.is_leaf && nd.b >= kLeafCountMask) cnt_ext[(size_t)nd.a] = (uint32_t)nd.b;
+
+    d.bytes = 0;
+    mr_status st;
+    if ((st = upload(d.nodes, nodes.data(), nodes.size(), d.bytes)) != MR_OK) return st;
+    if ((st = upload(d.tris, tris.data(), tris.size(), d.bytes)) != MR_OK) return st;
+    if ((st = upload(d.tri_prim, t.leaf_prims.data(), t.leaf_prims.size(), d.bytes)) != MR_OK) return st;
+    if ((st = upload(d.leaf_cnt_ext, cnt_ext.data(), cnt_ext.size(), d.bytes)) != MR_OK) return st;
+    if ((st = upload(d.v, m.v.data(), m.v.size(), d.bytes)) != MR_OK) return st;
+    if ((st = upload(d.n, m.n.data(), m.n.size(), d.bytes)) != MR_OK) return st;
+    if ((st = upload(d.vi, m.vi.data(), m.vi.size(), d.bytes)) != MR_OK) return st;
+    if ((st = upload(d.ni, m.ni.data(), m.ni.size(), d.bytes)) != MR_OK) return st;
+    const HostNode &root = t.nodes[0];
+    memcpy(d.root_lo, root.lo, sizeof(d.root_lo));
+    memcpy(d.root_hi, root.hi, sizeof(d.root_hi));
+    d.root_ref = ref_of(0);
+    d.n_inner = n_inner;
+    d.n_tris = nt;
+    d.stack_depth = t.max_depth + 1;
+    MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&s->d_stats), 2 * sizeof(unsigned long long)));
+    MR_HIP_CHECK(hipMemset(s->d_stats, 0, 2 * sizeof(unsigned long long)));
+    return MR_OK;
+}
+
+mr_status ensure_stage(mr_scene *s, uint64_t n) {
+    if (n <= s->stage_cap) return MR_OK;
+    (void)hipFree(s->d_stage_rays); (void)hipFree(s->d_stage_hits);
+    s->d_stage_rays = s->d_stage_hits = nullptr;
+    s->stage_cap = 0;
+    MR_HIP_CHECK(hipMalloc(&s->d_stage_rays, n * sizeof(mr_ray)));
+    MR_HIP_CHECK(hipMalloc(&s->d_stage_hits, n * sizeof(mr_hit)));
+    s->stage_cap = n;
+    return MR_OK;
+}
+
+mr_status require_built(const mr_scene *s) {
+    if (!s) return fail(MR_ERR_INVALID, "scene is NULL");
+    if (!s->built) return fail(MR_ERR_STATE, "mr_bvh_build has not been called on this scene");
+    return MR_OK;
+}
+
+mr_status require_device(const mr_scene *s) {
+    mr_status st = require_built(s);
+    if (st != MR_OK) return st;
+    if (!s->on_device)
+        return fail(MR_ERR_STATE, "scene was built host_only: nothing is resident on a device and there is no CPU fallback");
+    return MR_OK;
+}
+
+}  // namespace
+}  // namespace mr
+
+using namespace mr;
+
+extern "C" {
+
+const char *mr_last_error(void) { return g_err; }
+const char *mr_version(void) { return "miro_hip 0.1 (gfx950)"; }
+
+mr_status mr_scene_create(int32_t device, mr_scene **out) {
+    if (!out) return fail(MR_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (device < 0) return fail(MR_ERR_INVALID, "device %d is negative", device);
+    mr_scene *s = new (std::nothrow) mr_scene();
+    if (!s) return fail(MR_ERR_NOMEM, "out of host memory");
+    s->device = device;
+    *out = s;
+    return MR_OK;
+}
+
+mr_status mr_scene_destroy(mr_scene *s) {
+    if (!s) return MR_OK;
+    if (s->on_device) {
+        (void)hipSetDevice(s->device);
+        release_device(s);
+    }
+    delete s;
+    return MR_OK;
+}
+
+mr_status mr_scene_add_mesh(mr_scene *s, const mr_mesh_desc *mesh) {
+    if (!s || !mesh) return fail(MR_ERR_INVALID, "NULL argument");
+    if (s->built) return fail(MR_ERR_STATE, "scene is immutable after mr_bvh_build");
+    if ((mesh->n_vertices && !mesh->vertices) || (mesh->n_normals && !mesh->normals) ||
+        (mesh->n_triangles && (!mesh->vidx || !mesh->nidx)))
+        return fail(MR_ERR_INVALID, "mesh descriptor has NULL arrays");
+    for (uint32_t i = 0; i < 3 * mesh->n_triangles; i++) {
+        if (mesh->vidx[i] >= mesh->n_vertices) return fail(MR_ERR_INVALID, "vertex index %u out of range", mesh->vidx[i]);
+        if (mesh->nidx[i] >= mesh->n_normals) return fail(MR_ERR_INVALID, "normal index %u out of range", mesh->nidx[i]);
+    }
+    HostMesh &m = s->mesh;
+    const uint32_t vb = m.n_vertices(), nb = m.n_normals();
+    m.v.insert(m.v.end(), mesh->vertices, mesh->vertices + 3 * (size_t)mesh->n_vertices);
+    m.n.insert(m.n.end(), mesh->normals, mesh->normals + 3 * (size_t)mesh->n_normals);
+    for (uint32_t i = 0; i < 3 * mesh->n_triangles; i++) {
+        m.vi.push_back(mesh->vidx[i] + vb);
+        m.ni.push_back(mesh->nidx[i] + nb);
+    }
+    return MR_OK;
+}
+
+mr_status mr_scene_add_obj(mr_scene *s, const char *path, const float *ctm16, uint32_t *n_triangles_out) {
+    if (!s || !path) return fail(MR_ERR_INVALID, "NULL argument");
+    if (s->built) return fail(MR_ERR_STATE, "scene is immutable after mr_bvh_build");
+    return load_obj(path, ctm16, s->mesh, n_triangles_out);
+}
+
+mr_status mr_scene_add_triangle(mr_scene *s, const float v[9], const float n[9]) {
+    static const uint32_t idx[3] = {0, 1, 2};
+    mr_mesh_desc d;
+    d.vertices = v; d.n_vertices = 3;
+    d.normals = n;  d.n_normals = 3;
+    d.vidx = idx; d.nidx = idx; d.n_triangles = 1;
+    return mr_scene_add_mesh(s, &d);
+}
+
+mr_status mr_bvh_build(mr_scene *s, const mr_build_opts *opts) {
+    if (!s) return fail(MR_ERR_INVALID, "scene is NULL");
+    uint32_t leaf = 4;
+    if (opts) {
+        if (opts->builder != MR_BUILD_REFERENCE) return fail(MR_ERR_INVALID, "unknown builder %u", opts->builder);
+        if (opts->leaf_size) leaf = opts->leaf_size;
+    }
+    const bool host_only = opts && opts->host_only;
+    if (!host_only) {
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || count <= 0)
+            return fail(MR_ERR_HIP, "no HIP device available (%s); this library has no CPU fallback",
+                        e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        if (s->device >= count) return fail(MR_ERR_INVALID, "device %d out of range [0,%d)", s->device, count);
+        MR_HIP_CHECK(hipSetDevice(s->device));
+    }
+    if (s->on_device) release_device(s);
+    s->built = false;
+    s->on_device = false;
+    mr_status st = build_reference_tree(s->mesh, leaf, s->tree);
+    if (st != MR_OK) return st;
+    s->built = true;
+    if (host_only) return MR_OK;
+    st = flatten_and_upload(s);
+    if (st != MR_OK) { release_device(s); return st; }
+    s->on_device = true;
+    return MR_OK;
+}
+
+mr_status mr_scene_get_info(const mr_scene *s, mr_scene_info *info) {
+    if (!s || !info) return fail(MR_ERR_INVALID, "NULL argument");
+    memset(info, 0, sizeof(*info));
+    info->n_vertices = s->mesh.n_vertices();
+    info->n_normals = s->mesh.n_normals();
+    info->n_triangles = s->mesh.n_triangles();
+    info->built = s->built ? 1u : 0u;
+    info->device = s->device;
+    if (s->built) {
+        info->n_nodes = (uint32_t)s->tree.nodes.size();
+        info->n_leaves = s->tree.n_leaves;
+        info->max_depth = s->tree.max_depth;
+        info->leaf_size = s->tree.leaf_size;
+        info->device_bytes = s->dev.bytes;
+    }
+    return MR_OK;
+}
+
+mr_status mr_scene_get_mesh(const mr_scene *s, mr_mesh_desc *out) {
+    if (!s || !out) return fail(MR_ERR_INVALID, "NULL argument");
+    out->vertices = s->mesh.v.data(); out->n_vertices = s->mesh.n_vertices();
+    out->normals = s->mesh.n.data();  out->n_normals = s->mesh.n_normals();
+    out->vidx = s->mesh.vi.data();    out->nidx = s->mesh.ni.data();
+    out->n_triangles = s->mesh.n_triangles();
+    return MR_OK;
+}
+
+mr_status mr_scene_export_tree(const mr_scene *s, float *corners6, int32_t *meta3, uint32_t *leaf_prims) {
+    mr_status st = require_built(s);
+    if (st != MR_OK) return st;
+    const HostTree &t = s->tree;
+    for (size_t i = 0; i < t.nodes.size(); i++) {
+        if (corners6) {
+            memcpy(corners6 + 6 * i, t.nodes[i].lo, 3 * sizeof(float));
+            memcpy(corners6 + 6 * i + 3, t.nodes[i].hi, 3 * sizeof(float));
+        }
+        if (meta3) {
+            meta3[3 * i] = t.nodes[i].is_leaf;
+            meta3[3 * i + 1] = t.nodes[i].a;
+            meta3[3 * i + 2] = t.nodes[i].b;
+        }
+    }
+    if (leaf_prims) memcpy(leaf_prims, t.leaf_prims.data(), t.leaf_prims.size() * sizeof(uint32_t));
+    return MR_OK;
+}
+
+mr_status mr_trace(mr_scene *s, const mr_ray *rays, uint64_t n, mr_hit *hits, uint32_t flags, void *stream_v) {
+    mr_status st = require_device(s);
+    if (st != MR_OK) return st;
+    if (n == 0) return MR_OK;
+    if (!rays || !hits) return fail(MR_ERR_INVALID, "rays/hits is NULL");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    MR_HIP_CHECK(hipSetDevice(s->device));
+    const bool rays_dev = flags & MR_RAYS_ON_DEVICE, hits_dev = flags & MR_HITS_ON_DEVICE;
+    if ((rays_dev && (reinterpret_cast<uintptr_t>(rays) & 15)) || (hits_dev && (reinterpret_cast<uintptr_t>(hits) & 15)))
+        return fail(MR_ERR_INVALID, "device ray/hit buffers must be 16-byte aligned");
+    const mr_ray *d_rays = rays;
+    mr_hit *d_hits = hits;
+    if (!rays_dev || !hits_dev) {
+        if ((st = ensure_stage(s, n)) != MR_OK) return st;
+        if (!rays_dev) {
+            MR_HIP_CHECK(hipMemcpyAsync(s->d_stage_rays, rays, n * sizeof(mr_ray), hipMemcpyHostToDevice, stream));
+            d_rays = static_cast<const mr_ray *>(s->d_stage_rays);
+        }
+        if (!hits_dev) d_hits = static_cast<mr_hit *>(s->d_stage_hits);
+    }
+    TraceParams p;
+    p.nodes = s->dev.nodes; p.tris = s->dev.tris; p.tri_prim = s->dev.tri_prim; p.leaf_cnt_ext = s->dev.leaf_cnt_ext;
+    memcpy(p.root_lo, s->dev.root_lo, sizeof(p.root_lo));
+    memcpy(p.root_hi, s->dev.root_hi, sizeof(p.root_hi));
+    p.root_ref = s->dev.root_ref;
+    p.stack_depth = (int32_t)s->dev.stack_depth;
+    p.rays = d_rays; p.hits = d_hits; p.n = n; p.stats = s->d_stats;
+    if ((st = launch_trace(p, flags, stream)) != MR_OK) return st;
+    if (!hits_dev) {
+        MR_HIP_CHECK(hipMemcpyAsync(hits, d_hits, n * sizeof(mr_hit), hipMemcpyDeviceToHost, stream));
+        MR_HIP_CHECK(hipStreamSynchronize(stream));
+    } else if (!rays_dev) {
+        MR_HIP_CHECK(hipStreamSynchronize(stream));   // the staged host rays may be reused by the caller
+    }
+    return MR_OK;
+}
+
+mr_status mr_trace_get_stats(mr_scene *s, uint64_t *box_tests, uint64_t *tri_tests, int32_t reset) {
+    mr_status st = require_device(s);
+    if (st != MR_OK) return st;
+    MR_HIP_CHECK(hipSetDevice(s->device));
+    unsigned long long h[2] = {0, 0};
+    MR_HIP_CHECK(hipDeviceSynchronize());
+    MR_HIP_CHECK(hipMemcpy(h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+    if (box_tests) *box_tests = h[0];
+    if (tri_tests) *tri_tests = h[1];
+    if (reset) MR_HIP_CHECK(hipMemset(s->d_stats, 0, sizeof(h)));
+    return MR_OK;
+}
+
+mr_status mr_gen_eye_rays(mr_scene *s, const mr_camera *cam, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,
+                          uint32_t spp, uint32_t jitter, uint32_t seed, mr_ray *d_rays, void *stream) {
+    if (!s || !cam || !d_rays) return fail(MR_ERR_INVALID, "NULL argument");
+    if (W == 0 || H == 0 || spp == 0 || y1 < y0 || y1 > H) return fail(MR_ERR_INVALID, "bad image window");
+    if (reinterpret_cast<uintptr_t>(d_rays) & 15) return fail(MR_ERR_INVALID, "d_rays must be 16-byte aligned");
+    MR_HIP_CHECK(hipSetDevice(s->device));
+    return launch_eye_rays(*cam, W, H, y0, y1, spp, jitter, seed, d_rays, static_cast<hipStream_t>(stream));
+}
+
+mr_status mr_gen_shadow_rays(mr_scene *s, const mr_ray *d_rays, const mr_hit *d_hits, uint64_t n, const float light[3],
+                             mr_ray *d_out, uint32_t *d_src, uint64_t *d_count, void *stream) {
+    mr_status st = require_device(s);
+    if (st != MR_OK) return st;
+    if (!d_hits || !d_out || !d_count || !light) return fail(MR_ERR_INVALID, "NULL argument");
+    if (n > 0xFFFFFFFFull) return fail(MR_ERR_INVALID, "at most 2^32-1 rays per shadow batch");
+    MR_HIP_CHECK(hipSetDevice(s->device));
+    return launch_shadow_rays(s->dev, d_rays, d_hits, n, light, d_out, d_src,
+                              reinterpret_cast<unsigned long long *>(d_count), static_cast<hipStream_t>(stream));
+}
+
+mr_status mr_hit_attrs(mr_scene *s, const mr_hit *d_hits, uint64_t n, float *d_P, float *d_N, void *stream) {
+    mr_status st = require_device(s);
+    if (st != MR_OK) return st;
+    if (!d_hits) return fail(MR_ERR_INVALID, "d_hits is NULL");
+    MR_HIP_CHECK(hipSetDevice(s->device));
+    return launch_hit_attrs(s->dev, d_hits, n, d_P, d_N, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

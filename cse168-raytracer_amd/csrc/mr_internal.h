@@ -1,0 +1,120 @@
+// mr_internal.h -- shared declarations of the miro_hip library (not part of the ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "miro_hip.h"
+
+namespace mr {
+
+// ---------------------------------------------------------------------------------------
+// error plumbing: integer status + thread-local message (no exceptions across the ABI)
+// ---------------------------------------------------------------------------------------
+mr_status fail(mr_status code, const char *fmt, ...);
+#define MR_HIP_CHECK(expr)                                                              \
+    do {                                                                                \
+        hipError_t e__ = (expr);                                                        \
+        if (e__ != hipSuccess)                                                          \
+            return mr::fail(MR_ERR_HIP, "%s failed: %s (%s:%d)", #expr,                 \
+                            hipGetErrorString(e__), __FILE__, __LINE__);                \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------
+// host tree, DFS pre-order (what BVH::build produces, BVH.h:29-63)
+// ---------------------------------------------------------------------------------------
+struct HostNode {
+    float lo[3], hi[3];   // padded corners (m_corners[0], m_corners[1])
+    int32_t is_leaf;
+    int32_t a, b;         // inner: child node indices; leaf: [first, count) into leaf_prims
+    int32_t depth;
+};
+
+struct HostTree {
+    std::vector<HostNode> nodes;
+    std::vector<uint32_t> leaf_prims;   // object indices in leaf order
+    uint32_t n_leaves = 0, max_depth = 0, leaf_size = 4;
+};
+
+struct HostMesh {
+    std::vector<float> v, n;        // xyz triples
+    std::vector<uint32_t> vi, ni;   // 3 per triangle
+    uint32_t n_vertices() const { return (uint32_t)(v.size() / 3); }
+    uint32_t n_normals() const { return (uint32_t)(n.size() / 3); }
+    uint32_t n_triangles() const { return (uint32_t)(vi.size() / 3); }
+};
+
+// TriangleMesh::load semantics (TriangleMeshLoad.cpp:63-311): appends to `mesh`
+mr_status load_obj(const char *path, const float *ctm16, HostMesh &mesh, uint32_t *n_tris);
+// BVH::build semantics (BVH.cpp:60-339): identical tree to the reference's
+mr_status build_reference_tree(const HostMesh &mesh, uint32_t leaf_size, HostTree &tree);
+
+// ---------------------------------------------------------------------------------------
+// device layout (see DESIGN.md "Data layout in HBM")
+// ---------------------------------------------------------------------------------------
+// Inner node i = 4 consecutive float4 (one 64-byte record, one cache-line half):
+//   q0 = (c0.lo.x, c0.hi.x, c0.lo.y, c0.hi.y)
+//   q1 = (c1.lo.x, c1.hi.x, c1.lo.y, c1.hi.y)
+//   q2 = (c0.lo.z, c0.hi.z, c1.lo.z, c1.hi.z)
+//   q3 = (ref0, ref1, -, -) as int bits
+// ref >= 0: inner node index.  ref < 0: leaf, ~ref = (first << 4) | min(count, 15);
+// count == 15 means "read leaf_cnt_ext[first]" (only leaves cut off at depth 32 get there).
+// Triangle k (leaf order) = 3 consecutive float4 (48 bytes):
+//   (A.x, A.y, A.z, BmA.x) (BmA.y, BmA.z, CmA.x, CmA.y) (CmA.z, n.x, n.y, n.z),  n = BmA x CmA
+constexpr int kLeafCountBits = 4;
+constexpr int kLeafCountMask = 15;
+
+struct DeviceScene {
+    float4   *nodes = nullptr;         // 4 * n_inner
+    float4   *tris = nullptr;          // 3 * n_triangles (leaf order)
+    uint32_t *tri_prim = nullptr;      // leaf order -> prim id
+    uint32_t *leaf_cnt_ext = nullptr;  // leaf order position -> count (for count >= 15)
+    // original indexed mesh, for HitInfo reconstruction and shadow-ray origins
+    float    *v = nullptr, *n = nullptr;
+    uint32_t *vi = nullptr, *ni = nullptr;
+    float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
+    int32_t root_ref = 0;
+    uint32_t n_inner = 0, n_tris = 0, stack_depth = 1;
+    uint64_t bytes = 0;
+};
+
+struct TraceParams {
+    const float4   *nodes;
+    const float4   *tris;
+    const uint32_t *tri_prim;
+    const uint32_t *leaf_cnt_ext;
+    float root_lo[3], root_hi[3];
+    int32_t root_ref;
+    int32_t stack_depth;
+    const mr_ray *rays;
+    mr_hit *hits;
+    unsigned long long n;
+    unsigned long long *stats;   // [0] box tests, [1] triangle tests (MR_COUNT_STATS)
+};
+
+mr_status launch_trace(const TraceParams &p, uint32_t flags, hipStream_t stream);
+mr_status launch_eye_rays(const mr_camera &cam, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,
+                          uint32_t spp, uint32_t jitter, uint32_t seed, mr_ray *d_rays, hipStream_t stream);
+mr_status launch_shadow_rays(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits,
+                             unsigned long long n, const float light[3], mr_ray *d_out, uint32_t *d_src,
+                             unsigned long long *d_count, hipStream_t stream);
+mr_status launch_hit_attrs(const DeviceScene &ds, const mr_hit *d_hits, unsigned long long n,
+                           float *d_P, float *d_N, hipStream_t stream);
+
+}  // namespace mr
+
+struct mr_scene {
+    int32_t device = 0;
+    mr::HostMesh mesh;
+    mr::HostTree tree;
+    bool built = false;       // host tree exists
+    bool on_device = false;   // device records uploaded
+    mr::DeviceScene dev;
+    unsigned long long *d_stats = nullptr;
+    // grow-only staging buffers for host-pointer traces
+    void *d_stage_rays = nullptr, *d_stage_hits = nullptr;
+    uint64_t stage_cap = 0;
+};

@@ -1,0 +1,441 @@
+// mr_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the Miro intersection path.
+//
+//   trace_kernel        Scene::trace -> BVH::intersect -> BVH::intersectChildren -> Triangle::intersect
+//                       (Scene.cpp:214-268, BVH.cpp:438-658 scalar branch, Triangle.cpp:136-169)
+//   eye_rays_kernel     Camera::eyeRay (Camera.cpp:104-161)
+//   shadow_rays_kernel  Phong::shade shadow ray (Phong.cpp:80-97) + wave64 ballot compaction
+//   hit_attrs_kernel    HitInfo::P / ::N (Triangle.cpp:160,162)
+//
+// Compiled with -ffp-contract=off: in the default ("exact") mode every fp32 operation below is one
+// individually rounded IEEE op in the reference's order, so t / beta / gamma are bit-identical to the
+// reference's scalar build.  MR_MATH_FAST opts into explicit fmaf + v_rcp_f32.
+//
+// Traversal is pointer chasing, not a contraction: no MFMA.  One ray per lane, the pending-node stack
+// lives in LDS as stack[level][thread] (consecutive lanes -> consecutive banks, conflict-free for
+// ds_read/write_b32), nodes are 64-byte records fetched as 4 x dwordx4, triangles 48-byte records
+// fetched as 3 x dwordx4 (layout in mr_internal.h).
+#include <hip/hip_runtime.h>
+
+#include "mr_internal.h"
+
+namespace mr {
+namespace {
+
+constexpr int kBlock = 256;          // 4 waves per workgroup
+constexpr float kEps = 1e-4f;        // Miro.h:9
+constexpr float kInf = __builtin_huge_valf();
+
+struct Stats { unsigned long long box, tri; };
+
+// ---------------------------------------------------------------------------------------------------
+// slab test of one box.  EXACT keeps the reference's predicate structure literally (BVH.cpp:599-608):
+// NaNs (0 * inf when the origin sits on a slab plane of an axis the ray does not move along) fall
+// through every comparison.  `inv` is 1/d, correctly rounded; STRICT divides instead (bit-equal to
+// the reference's (corner - o) / d, used when the -DSTATS counters must match exactly).
+// ---------------------------------------------------------------------------------------------------
+template <bool STRICT>
+__device__ __forceinline__ void slab_axis(float lo, float hi, float o, float d, float inv, float &mn, float &mx) {
+    float t0, t1;
+    if (STRICT) { t0 = (lo - o) / d; t1 = (hi - o) / d; }
+    else        { t0 = (lo - o) * inv; t1 = (hi - o) * inv; }
+    const bool m = t0 > t1;
+    const float tnear = m ? t1 : t0, tfar = m ? t0 : t1;
+    if (tnear > mn) mn = tnear;
+    if (tfar < mx) mx = tfar;
+}
+
+__device__ __forceinline__ void slab_axis_fast(float lo, float hi, float o, float inv, float &mn, float &mx) {
+    const float t0 = (lo - o) * inv, t1 = (hi - o) * inv;
+    mn = fmaxf(mn, fminf(t0, t1));
+    mx = fminf(mx, fmaxf(t0, t1));
+}
+
+struct RayRegs {
+    float ox, oy, oz, dx, dy, dz;     // origin, direction
+    float ix, iy, iz;                 // 1/d
+    float mx_, my_, mz_;              // -d (Triangle.cpp:152 uses dot(-r.d, ...))
+    float tmin;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Triangle::intersect (Triangle.cpp:150-158).  q0..q2 = the 48-byte record.  Returns true when the
+// reference's reject test passes with tMax = best; outputs t, beta, gamma.
+// ---------------------------------------------------------------------------------------------------
+template <bool EXACT>
+__device__ __forceinline__ bool tri_test(const float4 q0, const float4 q1, const float4 q2, const RayRegs &r,
+                                         float tmax, float &t, float &beta, float &gamma) {
+    const float Ax = q0.x, Ay = q0.y, Az = q0.z;
+    const float Bx = q0.w, By = q1.x, Bz = q1.y;      // B - A
+    const float Cx = q1.z, Cy = q1.w, Cz = q2.x;      // C - A
+    const float nx = q2.y, ny = q2.z, nz = q2.w;      // (B-A) x (C-A)
+    const float px = r.ox - Ax, py = r.oy - Ay, pz = r.oz - Az;   // o - A
+    if (EXACT) {
+        const float ddotn = (r.mx_ * nx + r.my_ * ny) + r.mz_ * nz;
+        t = ((px * nx + py * ny) + pz * nz) / ddotn;
+        // cross(o-A, C-A)
+        const float ux = py * Cz - pz * Cy, uy = pz * Cx - px * Cz, uz = px * Cy - py * Cx;
+        beta = ((r.mx_ * ux + r.my_ * uy) + r.mz_ * uz) / ddotn;
+        // cross(B-A, o-A)
+        const float wx = By * pz - Bz * py, wy = Bz * px - Bx * pz, wz = Bx * py - By * px;
+        gamma = ((r.mx_ * wx + r.my_ * wy) + r.mz_ * wz) / ddotn;
+    } else {
+        const float ddotn = fmaf(r.mz_, nz, fmaf(r.my_, ny, r.mx_ * nx));
+        const float rcp = __builtin_amdgcn_rcpf(ddotn);
+        t = fmaf(pz, nz, fmaf(py, ny, px * nx)) * rcp;
+        const float ux = fmaf(py, Cz, -(pz * Cy)), uy = fmaf(pz, Cx, -(px * Cz)), uz = fmaf(px, Cy, -(py * Cx));
+        beta = fmaf(r.mz_, uz, fmaf(r.my_, uy, r.mx_ * ux)) * rcp;
+        const float wx = fmaf(By, pz, -(Bz * py)), wy = fmaf(Bz, px, -(Bx * pz)), wz = fmaf(Bx, py, -(By * px));
+        gamma = fmaf(r.mz_, wz, fmaf(r.my_, wy, r.mx_ * wx)) * rcp;
+    }
+    // reject iff beta < -eps || gamma < -eps || beta+gamma > 1+eps || t < tMin || t > tMax  (:158)
+    const bool reject = (beta < -kEps) || (gamma < -kEps) || (beta + gamma > 1 + kEps) || (t < r.tmin) || (t > tmax);
+    return !reject;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// closest-hit / any-hit traversal, one ray per lane
+// ---------------------------------------------------------------------------------------------------
+template <bool EXACT, bool ANY, bool STATS>
+__global__ __launch_bounds__(kBlock) void trace_kernel(TraceParams p) {
+    extern __shared__ int s_stack[];                  // [stack_depth][kBlock]
+    const int tid = threadIdx.x;
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
+    Stats st = {0ull, 0ull};
+
+    for (unsigned long long idx = (unsigned long long)blockIdx.x * kBlock + tid; idx < p.n; idx += stride) {
+        // two dwordx4 loads per lane, 32-byte stride: every byte of the fetched lines is used
+        const float4 ra = reinterpret_cast<const float4 *>(p.rays)[2 * idx];
+        const float4 rb = reinterpret_cast<const float4 *>(p.rays)[2 * idx + 1];
+        RayRegs r;
+        r.ox = ra.x; r.oy = ra.y; r.oz = ra.z; r.tmin = ra.w;
+        r.dx = rb.x; r.dy = rb.y; r.dz = rb.z;
+        const float tmax0 = rb.w;
+        r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+        r.mx_ = -r.dx; r.my_ = -r.dy; r.mz_ = -r.dz;
+
+        float best_t = tmax0;                         // minHit.t = tMax (BVH.cpp:444)
+        float best_b = 0.0f, best_g = 0.0f;
+        int best_pos = -1;                            // leaf-order position of the winning triangle
+
+        int sp = 0;                                   // entries of this lane on the LDS stack
+        int cur;
+        bool have;
+        {   // BVH::intersect root test (BVH.cpp:447-466)
+            float mn = -kInf, mx = kInf;
+            slab_axis<STATS>(p.root_lo[0], p.root_hi[0], r.ox, r.dx, r.ix, mn, mx);
+            slab_axis<STATS>(p.root_lo[1], p.root_hi[1], r.oy, r.dy, r.iy, mn, mx);
+            slab_axis<STATS>(p.root_lo[2], p.root_hi[2], r.oz, r.dz, r.iz, mn, mx);
+            if (STATS) st.box++;
+            have = !((mn > mx) || (mn > tmax0) || (mx < r.tmin));
+            cur = p.root_ref;
+        }
+
+        while (have) {
+            if (cur >= 0) {
+                // ---- inner node: test both children (BVH.cpp:593-624)
+                const float4 *nd = p.nodes + 4 * (size_t)cur;
+                const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2];
+                const int4 q3 = *reinterpret_cast<const int4 *>(nd + 3);
+                float mn0 = -kInf, mx0 = kInf, mn1 = -kInf, mx1 = kInf;
+                if (EXACT) {
+                    slab_axis<STATS>(q0.x, q0.y, r.ox, r.dx, r.ix, mn0, mx0);
+                    slab_axis<STATS>(q0.z, q0.w, r.oy, r.dy, r.iy, mn0, mx0);
+                    slab_axis<STATS>(q2.x, q2.y, r.oz, r.dz, r.iz, mn0, mx0);
+                    slab_axis<STATS>(q1.x, q1.y, r.ox, r.dx, r.ix, mn1, mx1);
+                    slab_axis<STATS>(q1.z, q1.w, r.oy, r.dy, r.iy, mn1, mx1);
+                    slab_axis<STATS>(q2.z, q2.w, r.oz, r.dz, r.iz, mn1, mx1);
+                } else {
+                    slab_axis_fast(q0.x, q0.y, r.ox, r.ix, mn0, mx0);
+                    slab_axis_fast(q0.z, q0.w, r.oy, r.iy, mn0, mx0);
+                    slab_axis_fast(q2.x, q2.y, r.oz, r.iz, mn0, mx0);
+                    slab_axis_fast(q1.x, q1.y, r.ox, r.ix, mn1, mx1);
+                    slab_axis_fast(q1.z, q1.w, r.oy, r.iy, mn1, mx1);
+                    slab_axis_fast(q2.z, q2.w, r.oz, r.iz, mn1, mx1);
+                }
+                // tMax of this call == best_t: nothing changed since the node was entered
+                const bool h0 = !((mn0 > mx0) || (mn0 > best_t) || (mx0 < r.tmin));
+                const bool h1 = !((mn1 > mx1) || (mn1 > best_t) || (mx1 < r.tmin));
+                // near-first; on equal entry distance child 0 goes first (:612-623)
+                const bool one_first = h1 && (!h0 || (mn0 > mn1));
+                if (h0 && h1) {
+                    s_stack[sp * kBlock + tid] = one_first ? q3.x : q3.y;
+                    sp++;
+                    cur = one_first ? q3.y : q3.x;
+                    if (STATS) st.box++;
+                } else if (h0 || h1) {
+                    cur = h0 ? q3.x : q3.y;
+                    if (STATS) st.box++;
+                } else if (sp > 0) {
+                    sp--;
+                    cur = s_stack[sp * kBlock + tid];
+                    if (STATS) st.box++;              // the far child is entered unconditionally (:640-650)
+                } else {
+                    have = false;
+                }
+            } else {
+                // ---- leaf (BVH.cpp:493-509)
+                const unsigned bits = ~(unsigned)cur;
+                const unsigned first = bits >> kLeafCountBits;
+                unsigned cnt = bits & kLeafCountMask;
+                if (cnt == kLeafCountMask) cnt = p.leaf_cnt_ext[first];
+                bool done = false;
+                for (unsigned k = 0; k < cnt; k++) {
+                    const float4 *tr = p.tris + 3 * (size_t)(first + k);
+                    float t, b, g;
+                    const bool ok = tri_test<EXACT>(tr[0], tr[1], tr[2], r, best_t, t, b, g);
+                    if (ok && t < best_t) {           // strict-less replacement (:500)
+                        best_t = t; best_b = b; best_g = g; best_pos = (int)(first + k);
+                        if (ANY) { done = true; break; }
+                    }
+                }
+                if (STATS) st.tri += cnt;
+                if (ANY && done) {
+                    have = false;
+                } else if (sp > 0) {
+                    sp--;
+                    cur = s_stack[sp * kBlock + tid];
+                    if (STATS) st.box++;
+                } else {
+                    have = false;
+                }
+            }
+        }
+
+        mr_hit h;
+        if (best_pos >= 0) {
+            h.t = best_t; h.prim = p.tri_prim[best_pos]; h.beta = best_b; h.gamma = best_g;
+        } else {
+            h.t = tmax0; h.prim = MR_MISS; h.beta = 0.0f; h.gamma = 0.0f;
+        }
+        reinterpret_cast<float4 *>(p.hits)[idx] = *reinterpret_cast<const float4 *>(&h);
+    }
+
+    if (STATS) {
+        // wave64 reduction, one atomic pair per wave
+        for (int off = 32; off > 0; off >>= 1) {
+            st.box += __shfl_down(st.box, off, 64);
+            st.tri += __shfl_down(st.tri, off, 64);
+        }
+        if ((tid & 63) == 0) {
+            atomicAdd(&p.stats[0], st.box);
+            atomicAdd(&p.stats[1], st.tri);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Camera::eyeRay (Camera.cpp:104-161).  The camera frame is computed on the host exactly as the
+// reference does; the per-pixel arithmetic below keeps the reference's operation order.
+// ---------------------------------------------------------------------------------------------------
+struct EyeFrame {
+    float eye[3], u[3], v[3], w[3];
+    float left, right, bottom, top;
+    uint32_t W, H, y0, spp, jitter, hbase;
+    unsigned long long n;
+};
+
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t x) {
+    const uint32_t state = x * 747796405u + 2891336453u;
+    const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+__device__ __forceinline__ float u01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
+
+__global__ __launch_bounds__(kBlock) void eye_rays_kernel(EyeFrame f, mr_ray *rays) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; k < f.n; k += stride) {
+        const unsigned long long pix_local = k / f.spp;
+        const uint32_t sm = (uint32_t)(k - pix_local * f.spp);
+        const uint32_t y = f.y0 + (uint32_t)(pix_local / f.W), x = (uint32_t)(pix_local % f.W);
+        float dx = 0.5f, dy = 0.5f;
+        if (f.jitter) {
+            const uint32_t pix = y * f.W + x;
+            const uint32_t b = pcg_hash(pcg_hash(f.hbase ^ pix) + sm);
+            dx = u01(pcg_hash(b));
+            dy = u01(pcg_hash(b ^ 0x68bc21ebu));
+        }
+        const float up = f.left + (f.right - f.left) * (((float)x + dx) / (float)f.W);
+        const float vp = f.bottom + (f.top - f.bottom) * (((float)y + dy) / (float)f.H);
+        float ddx = (up * f.u[0] + vp * f.v[0]) - f.w[0];
+        float ddy = (up * f.u[1] + vp * f.v[1]) - f.w[1];
+        float ddz = (up * f.u[2] + vp * f.v[2]) - f.w[2];
+        const float len = __fsqrt_rn((ddx * ddx + ddy * ddy) + ddz * ddz);
+        const float inv = 1.0f / len;
+        float4 a = make_float4(f.eye[0], f.eye[1], f.eye[2], 0.0f);
+        float4 b = make_float4(ddx * inv, ddy * inv, ddz * inv, 1e12f);     // MIRO_TMAX
+        reinterpret_cast<float4 *>(rays)[2 * k] = a;
+        reinterpret_cast<float4 *>(rays)[2 * k + 1] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// shadow rays (Phong.cpp:80-97): origin P + l*eps, direction l = normalise(L - P), tMax = |L - P|.
+// Hits are compacted wave-by-wave: ballot of hitting lanes, one atomicAdd per wave for the base,
+// mbcnt prefix for the lane's slot.
+// ---------------------------------------------------------------------------------------------------
+struct MeshPtrs { const float *v, *n; const uint32_t *vi, *ni; };
+
+__device__ __forceinline__ void hit_point(const MeshPtrs &m, uint32_t prim, float beta, float gamma,
+                                          float &Px, float &Py, float &Pz) {
+    const uint32_t ia = m.vi[3 * (size_t)prim], ib = m.vi[3 * (size_t)prim + 1], ic = m.vi[3 * (size_t)prim + 2];
+    const float ax = m.v[3 * (size_t)ia], ay = m.v[3 * (size_t)ia + 1], az = m.v[3 * (size_t)ia + 2];
+    const float bx = m.v[3 * (size_t)ib] - ax, by = m.v[3 * (size_t)ib + 1] - ay, bz = m.v[3 * (size_t)ib + 2] - az;
+    const float cx = m.v[3 * (size_t)ic] - ax, cy = m.v[3 * (size_t)ic + 1] - ay, cz = m.v[3 * (size_t)ic + 2] - az;
+    Px = (ax + beta * bx) + gamma * cx;               // A + beta*BmA + gamma*CmA (Triangle.cpp:160)
+    Py = (ay + beta * by) + gamma * cy;
+    Pz = (az + beta * bz) + gamma * cz;
+}
+
+__global__ __launch_bounds__(kBlock) void shadow_rays_kernel(MeshPtrs m, const mr_hit *hits, unsigned long long n,
+                                                             float Lx, float Ly, float Lz, mr_ray *out,
+                                                             uint32_t *src, unsigned long long *count) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
+    const unsigned long long n_round = (n + 63ull) & ~63ull;       // keep whole waves in the loop
+    for (unsigned long long k = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; k < n_round; k += stride) {
+        float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool is_hit = false;
+        if (k < n) {
+            h = reinterpret_cast<const float4 *>(hits)[k];
+            is_hit = __float_as_uint(h.y) != MR_MISS;
+        }
+        const unsigned long long mask = __ballot(is_hit);
+        if (mask == 0ull) continue;
+        unsigned long long base = 0;
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll((long long)mask) - 1;
+        if (lane == leader) base = atomicAdd(count, (unsigned long long)__popcll(mask));
+        base = __shfl(base, leader, 64);
+        if (is_hit) {
+            const unsigned long long slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+            float Px, Py, Pz;
+            hit_point(m, __float_as_uint(h.y), h.z, h.w, Px, Py, Pz);
+            float lx = Lx - Px, ly = Ly - Py, lz = Lz - Pz;           // PointLight::getLightDirection
+            const float falloff = (lx * lx + ly * ly) + lz * lz;
+            const float len = __fsqrt_rn(falloff);
+            const float inv = 1.0f / len;                              // l /= sqrt(falloff)
+            lx *= inv; ly *= inv; lz *= inv;
+            float4 a = make_float4(Px + lx * kEps, Py + ly * kEps, Pz + lz * kEps, 0.0f);
+            float4 b = make_float4(lx, ly, lz, len);
+            reinterpret_cast<float4 *>(out)[2 * slot] = a;
+            reinterpret_cast<float4 *>(out)[2 * slot + 1] = b;
+            if (src) src[slot] = (uint32_t)k;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void hit_attrs_kernel(MeshPtrs m, const mr_hit *hits, unsigned long long n,
+                                                           float *P, float *N) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; k < n; k += stride) {
+        const float4 h = reinterpret_cast<const float4 *>(hits)[k];
+        const uint32_t prim = __float_as_uint(h.y);
+        float Px = 0.f, Py = 0.f, Pz = 0.f, Nx = 0.f, Ny = 1.f, Nz = 0.f;     // HitInfo defaults (Ray.h:31-34)
+        if (prim != MR_MISS) {
+            const float beta = h.z, gamma = h.w;
+            hit_point(m, prim, beta, gamma, Px, Py, Pz);
+            const uint32_t ia = m.ni[3 * (size_t)prim], ib = m.ni[3 * (size_t)prim + 1], ic = m.ni[3 * (size_t)prim + 2];
+            const float alpha = 1 - beta - gamma;
+            Nx = (alpha * m.n[3 * (size_t)ia]     + beta * m.n[3 * (size_t)ib])     + gamma * m.n[3 * (size_t)ic];
+            Ny = (alpha * m.n[3 * (size_t)ia + 1] + beta * m.n[3 * (size_t)ib + 1]) + gamma * m.n[3 * (size_t)ic + 1];
+            Nz = (alpha * m.n[3 * (size_t)ia + 2] + beta * m.n[3 * (size_t)ib + 2]) + gamma * m.n[3 * (size_t)ic + 2];
+        }
+        if (P) { P[3 * k] = Px; P[3 * k + 1] = Py; P[3 * k + 2] = Pz; }
+        if (N) { N[3 * k] = Nx; N[3 * k + 1] = Ny; N[3 * k + 2] = Nz; }
+    }
+}
+
+inline unsigned grid_for(unsigned long long n) {
+    // memory/latency-bound kernels: cap the grid and grid-stride the rest (256 CUs x 8 blocks)
+    unsigned long long blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > 256ull * 32ull) blocks = 256ull * 32ull;
+    if (blocks == 0) blocks = 1;
+    return (unsigned)blocks;
+}
+
+template <bool EXACT, bool ANY, bool STATS>
+mr_status launch_trace_t(const TraceParams &p, hipStream_t stream) {
+    const size_t lds = (size_t)p.stack_depth * kBlock * sizeof(int);
+    if (lds > 160 * 1024) return fail(MR_ERR_INVALID, "traversal stack of depth %d does not fit in LDS", p.stack_depth);
+    if (lds > 64 * 1024)
+        MR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&trace_kernel<EXACT, ANY, STATS>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((trace_kernel<EXACT, ANY, STATS>), dim3(grid_for(p.n)), dim3(kBlock), lds, stream, p);
+    MR_HIP_CHECK(hipGetLastError());
+    return MR_OK;
+}
+
+}  // namespace
+
+mr_status launch_trace(const TraceParams &p, uint32_t flags, hipStream_t stream) {
+    if (p.n == 0) return MR_OK;
+    const bool fast = flags & MR_MATH_FAST, any = flags & MR_TRACE_ANY, stats = flags & MR_COUNT_STATS;
+    if (stats) {
+        // counting mode is diagnostic: always the strict-division exact kernel
+        return any ? launch_trace_t<true, true, true>(p, stream) : launch_trace_t<true, false, true>(p, stream);
+    }
+    if (fast) return any ? launch_trace_t<false, true, false>(p, stream) : launch_trace_t<false, false, false>(p, stream);
+    return any ? launch_trace_t<true, true, false>(p, stream) : launch_trace_t<true, false, false>(p, stream);
+}
+
+mr_status launch_eye_rays(const mr_camera &cam, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,
+                          uint32_t spp, uint32_t jitter, uint32_t seed, mr_ray *d_rays, hipStream_t stream) {
+    // camera frame on the host, in the reference's order of operations (Camera.h:79-110, Camera.cpp:113-124)
+    auto unit3 = [](float *a) {
+        const float len = sqrtf((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
+        const float inv = 1.0f / len;
+        a[0] *= inv; a[1] *= inv; a[2] *= inv;
+    };
+    auto cross3 = [](const float *a, const float *b, float *o) {
+        o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    EyeFrame f;
+    float up[3] = {cam.up[0], cam.up[1], cam.up[2]};
+    unit3(up);
+    float view[3] = {cam.lookat[0] - cam.eye[0], cam.lookat[1] - cam.eye[1], cam.lookat[2] - cam.eye[2]};
+    unit3(view);
+    f.w[0] = -view[0]; f.w[1] = -view[1]; f.w[2] = -view[2];
+    unit3(f.w);
+    cross3(up, f.w, f.u);
+    unit3(f.u);
+    cross3(f.w, f.u, f.v);
+    const float PI = 3.1415926535897932384626433832795028841972f;
+    const float DegToRad = PI / 180.0f, HalfDegToRad = DegToRad / 2.0f;
+    const float aspect = (float)W / (float)H;
+    f.top = tanf(cam.fov_deg * HalfDegToRad);
+    f.right = aspect * f.top; f.bottom = -f.top; f.left = -f.right;
+    f.eye[0] = cam.eye[0]; f.eye[1] = cam.eye[1]; f.eye[2] = cam.eye[2];
+    f.W = W; f.H = H; f.y0 = y0; f.spp = spp; f.jitter = jitter;
+    {   // host copy of pcg_hash
+        uint32_t state = seed * 747796405u + 2891336453u;
+        uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+        f.hbase = (word >> 22u) ^ word;
+    }
+    f.n = (unsigned long long)(y1 - y0) * W * spp;
+    if (f.n == 0) return MR_OK;
+    hipLaunchKernelGGL(eye_rays_kernel, dim3(grid_for(f.n)), dim3(kBlock), 0, stream, f, d_rays);
+    MR_HIP_CHECK(hipGetLastError());
+    return MR_OK;
+}
+
+mr_status launch_shadow_rays(const DeviceScene &ds, const mr_ray *, const mr_hit *d_hits, unsigned long long n,
+                             const float light[3], mr_ray *d_out, uint32_t *d_src, unsigned long long *d_count,
+                             hipStream_t stream) {
+    MR_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), stream));
+    if (n == 0) return MR_OK;
+    MeshPtrs m{ds.v, ds.n, ds.vi, ds.ni};
+    hipLaunchKernelGGL(shadow_rays_kernel, dim3(grid_for(n)), dim3(kBlock), 0, stream, m, d_hits, n,
+                       light[0], light[1], light[2], d_out, d_src, d_count);
+    MR_HIP_CHECK(hipGetLastError());
+    return MR_OK;
+}
+
+mr_status launch_hit_attrs(const DeviceScene &ds, const mr_hit *d_hits, unsigned long long n, float *d_P, float *d_N,
+                           hipStream_t stream) {
+    if (n == 0) return MR_OK;
+    MeshPtrs m{ds.v, ds.n, ds.vi, ds.ni};
+    hipLaunchKernelGGL(hit_attrs_kernel, dim3(grid_for(n)), dim3(kBlock), 0, stream, m, d_hits, n, d_P, d_N);
+    MR_HIP_CHECK(hipGetLastError());
+    return MR_OK;
+}
+
+}  // namespace mr

@@ -1,0 +1,14 @@
+"""miro_amd -- Python glue over the C ABI of include/miro_hip.h (test / bench harness only).
+
+The product is the shared library ``cse168-raytracer_amd/lib/libmiro_hip.so`` (hand-written HIP for
+gfx950 behind an extern "C" boundary) and the C++ shim in ``cse168-raytracer_amd/host``.  This package
+binds the C ABI with ctypes so that tests and bench.py can drive it; torch is used for device buffers,
+streams and torch.distributed only.  There is no CPU fallback anywhere in this package: if the library
+is missing it raises, and on a machine without a GPU every device call returns MR_ERR_HIP.
+"""
+from .binding import (  # noqa: F401
+    HIT_DTYPE, RAY_DTYPE, MISS, MiroError, Scene, lib, lib_path, load_library,
+    MR_TRACE_CLOSEST, MR_TRACE_ANY, MR_RAYS_ON_DEVICE, MR_HITS_ON_DEVICE, MR_MATH_FAST, MR_COUNT_STATS,
+    EXPORTED_SYMBOLS,
+)
+from . import scenes  # noqa: F401

@@ -1,0 +1,273 @@
+"""ctypes binding of libmiro_hip.so.  Names follow the reference: Scene.addObject-style assembly,
+Scene.preCalc() -> BVH::build, Scene.trace() (batched)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = os.path.join(_PKG, "lib", "libmiro_hip.so")
+
+RAY_DTYPE = np.dtype([("ox", "<f4"), ("oy", "<f4"), ("oz", "<f4"), ("tmin", "<f4"),
+                      ("dx", "<f4"), ("dy", "<f4"), ("dz", "<f4"), ("tmax", "<f4")])
+HIT_DTYPE = np.dtype([("t", "<f4"), ("prim", "<u4"), ("beta", "<f4"), ("gamma", "<f4")])
+MISS = 0xFFFFFFFF
+
+MR_TRACE_CLOSEST = 0
+MR_TRACE_ANY = 1 << 0
+MR_RAYS_ON_DEVICE = 1 << 1
+MR_HITS_ON_DEVICE = 1 << 2
+MR_MATH_FAST = 1 << 3
+MR_COUNT_STATS = 1 << 4
+
+MR_OK, MR_ERR_INVALID, MR_ERR_IO, MR_ERR_NOMEM, MR_ERR_HIP, MR_ERR_STATE = 0, -1, -2, -3, -4, -5
+
+# every symbol include/miro_hip.h declares (tests check the library exports each one)
+EXPORTED_SYMBOLS = [
+    "mr_scene_create", "mr_scene_destroy", "mr_scene_add_mesh", "mr_scene_add_obj", "mr_scene_add_triangle",
+    "mr_bvh_build", "mr_scene_get_info", "mr_scene_get_mesh", "mr_scene_export_tree",
+    "mr_trace", "mr_trace_get_stats", "mr_gen_eye_rays", "mr_gen_shadow_rays", "mr_hit_attrs",
+    "mr_last_error", "mr_version",
+]
+
+
+class MiroError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("miro_hip status %d: %s" % (status, msg))
+        self.status = status
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [("vertices", C.POINTER(C.c_float)), ("n_vertices", C.c_uint32),
+                ("normals", C.POINTER(C.c_float)), ("n_normals", C.c_uint32),
+                ("vidx", C.POINTER(C.c_uint32)), ("nidx", C.POINTER(C.c_uint32)),
+                ("n_triangles", C.c_uint32)]
+
+
+class BuildOpts(C.Structure):
+    _fields_ = [("leaf_size", C.c_uint32), ("builder", C.c_uint32), ("host_only", C.c_uint32),
+                ("reserved", C.c_uint32 * 5)]
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("n_vertices", C.c_uint32), ("n_normals", C.c_uint32), ("n_triangles", C.c_uint32),
+                ("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("max_depth", C.c_uint32),
+                ("leaf_size", C.c_uint32), ("built", C.c_uint32), ("device_bytes", C.c_uint64),
+                ("device", C.c_int32), ("reserved", C.c_uint32 * 3)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("eye", C.c_float * 3), ("lookat", C.c_float * 3), ("up", C.c_float * 3),
+                ("fov_deg", C.c_float)]
+
+
+class FrameDesc(C.Structure):
+    _fields_ = [("cam", Camera), ("light", C.c_float * 3), ("W", C.c_uint32), ("H", C.c_uint32),
+                ("y0", C.c_uint32), ("y1", C.c_uint32), ("spp", C.c_uint32), ("jitter", C.c_uint32),
+                ("seed", C.c_uint32), ("flags", C.c_uint32), ("wattage", C.c_float),
+                ("reserved", C.c_uint32 * 3)]
+
+
+class FrameStats(C.Structure):
+    _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("primary_hits", C.c_uint64),
+                ("occluded", C.c_uint64)]
+
+
+def lib_path():
+    return _LIB
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libmiro_hip.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    path = path or _LIB
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            "%s not found: build it with `make -C cse168-raytracer_amd` or __graft_entry__.build()" % path)
+    try:  # share torch's HIP runtime (same soname) when torch is present
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover
+        pass
+    L = C.CDLL(path)
+    vp, f32p, u32p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+    L.mr_last_error.restype = C.c_char_p
+    L.mr_version.restype = C.c_char_p
+    L.mr_scene_create.argtypes = [C.c_int32, C.POINTER(vp)]
+    L.mr_scene_destroy.argtypes = [vp]
+    L.mr_scene_add_mesh.argtypes = [vp, C.POINTER(MeshDesc)]
+    L.mr_scene_add_obj.argtypes = [vp, C.c_char_p, f32p, u32p]
+    L.mr_scene_add_triangle.argtypes = [vp, f32p, f32p]
+    L.mr_bvh_build.argtypes = [vp, C.POINTER(BuildOpts)]
+    L.mr_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
+    L.mr_scene_get_mesh.argtypes = [vp, C.POINTER(MeshDesc)]
+    L.mr_scene_export_tree.argtypes = [vp, f32p, C.POINTER(C.c_int32), u32p]
+    L.mr_trace.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp]
+    L.mr_trace_get_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]
+    L.mr_gen_eye_rays.argtypes = [vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                  C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
+    L.mr_gen_shadow_rays.argtypes = [vp, vp, vp, C.c_uint64, f32p, vp, vp, vp, vp]
+    L.mr_hit_attrs.argtypes = [vp, vp, C.c_uint64, vp, vp, vp]
+    if hasattr(L, "mr_render_frame"):
+        L.mr_render_frame.argtypes = [vp, C.POINTER(FrameDesc), vp, vp, C.POINTER(FrameStats), vp]
+    for name in EXPORTED_SYMBOLS:
+        if hasattr(L, name) and getattr(L, name).restype is C.c_int:
+            getattr(L, name).restype = C.c_int32
+    _lib = L
+    return L
+
+
+def lib():
+    return _lib if _lib is not None else load_library()
+
+
+def _check(st):
+    if st != MR_OK:
+        raise MiroError(st, lib().mr_last_error().decode("utf-8", "replace"))
+
+
+def _f32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _u32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def make_camera(eye, lookat, up, fov_deg):
+    cam = Camera()
+    cam.eye[:] = eye
+    cam.lookat[:] = lookat
+    cam.up[:] = up
+    cam.fov_deg = fov_deg
+    return cam
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        return None
+    return C.c_void_p(int(getattr(stream, "cuda_stream", stream)))
+
+
+class Scene:
+    """Scene (Scene.h:14-73) on one device: addObject-style assembly, preCalc() = BVH::build, trace()."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        _check(self.L.mr_scene_create(device, C.byref(self.h)))
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mr_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- assembly (Scene::addObject over TriangleMesh triangles, assignment2.cpp:449-461)
+    def add_obj(self, path, ctm=None):
+        m = None
+        if ctm is not None:
+            m = np.ascontiguousarray(ctm, dtype=np.float32).reshape(16)
+        n = C.c_uint32(0)
+        _check(self.L.mr_scene_add_obj(self.h, os.fsencode(path), _f32p(m) if m is not None else None, C.byref(n)))
+        return n.value
+
+    def add_triangle(self, verts, normals):
+        v = np.ascontiguousarray(verts, dtype=np.float32).reshape(9)
+        n = np.ascontiguousarray(normals, dtype=np.float32).reshape(9)
+        _check(self.L.mr_scene_add_triangle(self.h, _f32p(v), _f32p(n)))
+        return 1
+
+    def add_arrays(self, v, n, vi, ni):
+        v = np.ascontiguousarray(v, dtype=np.float32).reshape(-1, 3)
+        n = np.ascontiguousarray(n, dtype=np.float32).reshape(-1, 3)
+        vi = np.ascontiguousarray(vi, dtype=np.uint32).reshape(-1, 3)
+        ni = np.ascontiguousarray(ni, dtype=np.uint32).reshape(-1, 3)
+        d = MeshDesc(_f32p(v), len(v), _f32p(n), len(n), _u32p(vi), _u32p(ni), len(vi))
+        _check(self.L.mr_scene_add_mesh(self.h, C.byref(d)))
+        return len(vi)
+
+    # ---- Scene::preCalc -> BVH::build (Scene.cpp:72)
+    def build(self, leaf_size=4, host_only=False):
+        o = BuildOpts()
+        o.leaf_size = leaf_size
+        o.builder = 0
+        o.host_only = 1 if host_only else 0
+        _check(self.L.mr_bvh_build(self.h, C.byref(o)))
+        return self.info()
+
+    preCalc = build
+
+    def info(self):
+        i = SceneInfo()
+        _check(self.L.mr_scene_get_info(self.h, C.byref(i)))
+        return i
+
+    def arrays(self):
+        d = MeshDesc()
+        _check(self.L.mr_scene_get_mesh(self.h, C.byref(d)))
+        def arr(p, n, dt):
+            if n == 0:
+                return np.zeros((0, 3), dt)
+            return np.ctypeslib.as_array(p, shape=(n, 3)).copy()
+        return (arr(d.vertices, d.n_vertices, np.float32), arr(d.normals, d.n_normals, np.float32),
+                arr(d.vidx, d.n_triangles, np.uint32), arr(d.nidx, d.n_triangles, np.uint32))
+
+    def export_tree(self):
+        i = self.info()
+        corners = np.zeros((i.n_nodes, 6), np.float32)
+        meta = np.zeros((i.n_nodes, 3), np.int32)
+        prims = np.zeros(max(i.n_triangles, 1), np.uint32)
+        _check(self.L.mr_scene_export_tree(self.h, _f32p(corners), meta.ctypes.data_as(C.POINTER(C.c_int32)), _u32p(prims)))
+        return corners, meta, prims[:i.n_triangles]
+
+    # ---- Scene::trace, batched
+    def trace(self, rays, flags=0):
+        """Host numpy rays (RAY_DTYPE) -> host numpy hits (HIT_DTYPE)."""
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.empty(len(rays), HIT_DTYPE)
+        flags &= ~(MR_RAYS_ON_DEVICE | MR_HITS_ON_DEVICE)
+        _check(self.L.mr_trace(self.h, rays.ctypes.data, len(rays), hits.ctypes.data, flags, None))
+        return hits
+
+    def trace_device(self, d_rays, n, d_hits, flags=0, stream=None):
+        """Device buffers (torch tensors or raw pointers); only enqueues work."""
+        rp = d_rays.data_ptr() if hasattr(d_rays, "data_ptr") else int(d_rays)
+        hp = d_hits.data_ptr() if hasattr(d_hits, "data_ptr") else int(d_hits)
+        _check(self.L.mr_trace(self.h, rp, n, hp, flags | MR_RAYS_ON_DEVICE | MR_HITS_ON_DEVICE, _stream_ptr(stream)))
+
+    def stats(self, reset=True):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(self.L.mr_trace_get_stats(self.h, C.byref(a), C.byref(b), 1 if reset else 0))
+        return a.value, b.value
+
+    # ---- callers on the device
+    def gen_eye_rays(self, cam, W, H, d_rays, y0=0, y1=None, spp=1, jitter=False, seed=168, stream=None):
+        y1 = H if y1 is None else y1
+        _check(self.L.mr_gen_eye_rays(self.h, C.byref(cam), W, H, y0, y1, spp, 1 if jitter else 0, seed,
+                                      d_rays.data_ptr(), _stream_ptr(stream)))
+        return (y1 - y0) * W * spp
+
+    def gen_shadow_rays(self, d_rays, d_hits, n, light, d_out, d_src, d_count, stream=None):
+        l = np.ascontiguousarray(light, dtype=np.float32)
+        _check(self.L.mr_gen_shadow_rays(self.h, d_rays.data_ptr() if d_rays is not None else None, d_hits.data_ptr(), n,
+                                         _f32p(l), d_out.data_ptr(), d_src.data_ptr() if d_src is not None else None,
+                                         d_count.data_ptr(), _stream_ptr(stream)))
+
+    def hit_attrs(self, d_hits, n, d_P, d_N, stream=None):
+        _check(self.L.mr_hit_attrs(self.h, d_hits.data_ptr(), n, d_P.data_ptr() if d_P is not None else None,
+                                   d_N.data_ptr() if d_N is not None else None, _stream_ptr(stream)))
+
+    def render_frame(self, frame, d_image, d_work, stream=None):
+        st = FrameStats()
+        _check(self.L.mr_render_frame(self.h, C.byref(frame), d_image.data_ptr(),
+                                      d_work.data_ptr() if d_work is not None else None, C.byref(st), _stream_ptr(stream)))
+        return st

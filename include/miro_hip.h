@@ -1,0 +1,144 @@
+/*
+ * miro_hip.h -- C ABI of the MI355X-native intersection path for the Miro ray tracer
+ * (hallgeirl/cse168-raytracer).  Plain C, plain pointers and sizes; no C++ or torch types.
+ *
+ * The reference has no FFI layer: its hot path is the C++ surface
+ *     bool Scene::trace(HitInfo&, const Ray&, float tMin, float tMax) const   Scene.h:38-39, Scene.cpp:214-268
+ *     void BVH::build(Objects*, int depth)                                    BVH.h:33,      BVH.cpp:60-339
+ *     bool BVH::intersect(HitInfo&, const Ray&, float tMin, float tMax) const BVH.h:35-36,   BVH.cpp:438-469
+ * called from Scene.cpp:72 (build), :217/:278/:539 and Phong.cpp:97 (trace).  The entry points
+ * below are what a binding for that surface binds: scene assembly (Scene::addObject,
+ * TriangleMesh::load), BVH::build, and a *batched* Scene::trace (a single-ray call is a
+ * batch of one).  cse168-raytracer_amd/host/miro_shim.hpp re-creates the C++ signatures on top
+ * of these functions; INTEGRATION.md shows the reference-side glue.
+ *
+ * All functions return MR_OK (0) or a negative mr_status; mr_last_error() gives a
+ * thread-local message.  No exception crosses this boundary.  There is NO CPU fallback:
+ * without a HIP device every device-touching call fails with MR_ERR_HIP.
+ */
+#ifndef MIRO_HIP_H
+#define MIRO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t mr_status;
+enum {
+    MR_OK          =  0,
+    MR_ERR_INVALID = -1,   /* bad argument */
+    MR_ERR_IO      = -2,   /* file could not be opened (TriangleMesh::load returns false, TriangleMeshLoad.cpp:66-71) */
+    MR_ERR_NOMEM   = -3,
+    MR_ERR_HIP     = -4,   /* HIP runtime error or no device */
+    MR_ERR_STATE   = -5    /* call out of order (trace before build, add after build) */
+};
+
+/* Ray (Ray.h:40-84): origin, direction and the [tMin,tMax] interval that Scene::trace
+ * takes as separate arguments.  32 bytes, two float4 loads per lane on the device. */
+typedef struct mr_ray { float ox, oy, oz, tmin, dx, dy, dz, tmax; } mr_ray;
+
+/* HitInfo (Ray.h:21-38) in its minimal device form.  prim indexes triangles in
+ * Scene::addObject order (= concatenated mesh order); beta/gamma are the locals of
+ * Triangle.cpp:155-156.  On a miss prim == MR_MISS, t == tmax (BVH.cpp:444), beta=gamma=0.
+ * P, N, material, object are rebuilt by the shim (Triangle.cpp:160-166). 16 bytes. */
+typedef struct mr_hit { float t; uint32_t prim; float beta, gamma; } mr_hit;
+#define MR_MISS 0xFFFFFFFFu
+
+/* Indexed triangle mesh as TriangleMesh stores it (TriangleMesh.h:27-67). */
+typedef struct mr_mesh_desc {
+    const float    *vertices;  uint32_t n_vertices;   /* xyz triples */
+    const float    *normals;   uint32_t n_normals;    /* xyz triples */
+    const uint32_t *vidx;                             /* 3 per triangle */
+    const uint32_t *nidx;                             /* 3 per triangle */
+    uint32_t        n_triangles;
+} mr_mesh_desc;
+
+typedef struct mr_build_opts {
+    uint32_t leaf_size;     /* OBJECTS_PER_LEAF (BVH.h:59,61): 4 = scalar reference build (default when 0) */
+    uint32_t builder;       /* MR_BUILD_REFERENCE (0): the reference's binary-search split, identical tree */
+    uint32_t host_only;     /* 1: build the tree on the host and skip the device upload (tree inspection,
+                               CPU-only tooling); mr_trace on such a scene fails with MR_ERR_STATE */
+    uint32_t reserved[5];
+} mr_build_opts;
+enum { MR_BUILD_REFERENCE = 0 };
+
+typedef struct mr_scene_info {
+    uint32_t n_vertices, n_normals, n_triangles;
+    uint32_t n_nodes, n_leaves, max_depth;            /* Stats::BVH_Nodes / BVH_LeafNodes (BVH.cpp:64,88) */
+    uint32_t leaf_size, built;
+    uint64_t device_bytes;                            /* node + triangle + index arrays resident in HBM */
+    int32_t  device;
+    uint32_t reserved[3];
+} mr_scene_info;
+
+typedef struct mr_camera {                            /* Camera.h:53-60 */
+    float eye[3], lookat[3], up[3], fov_deg;
+} mr_camera;
+
+/* mr_trace flags */
+enum {
+    MR_TRACE_CLOSEST  = 0u,        /* Scene::trace semantics (closest hit, strict-less replacement) */
+    MR_TRACE_ANY      = 1u << 0,   /* stop at the first accepted hit; legal for shadow batches only when the
+                                      scene has no refractive material (Phong.cpp:99-113) */
+    MR_RAYS_ON_DEVICE = 1u << 1,   /* rays is a device pointer */
+    MR_HITS_ON_DEVICE = 1u << 2,   /* hits is a device pointer */
+    MR_MATH_FAST      = 1u << 3,   /* fused multiply-add + v_rcp_f32 (within 1e-5 rel. of the reference);
+                                      default is the bit-exact IEEE expression tree of Triangle.cpp:150-156 */
+    MR_COUNT_STATS    = 1u << 4    /* accumulate -DSTATS counters (BVH.cpp:461,496,632,643) */
+};
+
+typedef struct mr_scene mr_scene;
+
+/* ---- scene assembly: Scene::addObject / TriangleMesh::load / createSingleTriangle -------------- */
+mr_status mr_scene_create(int32_t device, mr_scene **out);
+mr_status mr_scene_destroy(mr_scene *scene);
+/* copies the arrays; triangles are appended in order (assignment2.cpp:449-461) */
+mr_status mr_scene_add_mesh(mr_scene *scene, const mr_mesh_desc *mesh);
+/* TriangleMesh::load(file, ctm) (TriangleMeshLoad.cpp:63-311); ctm = 16 floats row-major or NULL */
+mr_status mr_scene_add_obj(mr_scene *scene, const char *path, const float *ctm16, uint32_t *n_triangles_out);
+/* TriangleMesh::createSingleTriangle + setV1..3/setN1..3 (TriangleMeshLoad.cpp:15-56) */
+mr_status mr_scene_add_triangle(mr_scene *scene, const float v[9], const float n[9]);
+
+/* ---- BVH::build (BVH.cpp:60-339) via Scene::preCalc (Scene.cpp:50-84); uploads the scene ------- */
+mr_status mr_bvh_build(mr_scene *scene, const mr_build_opts *opts);
+
+mr_status mr_scene_get_info(const mr_scene *scene, mr_scene_info *info);
+/* host copies of the merged mesh (for the shim's P/N/material reconstruction) */
+mr_status mr_scene_get_mesh(const mr_scene *scene, mr_mesh_desc *out);
+/* tree in DFS pre-order: corners6[n_nodes*6], meta3[n_nodes*3] = (is_leaf, child0|first, child1|count),
+ * leaf_prims[n_triangles].  Any pointer may be NULL. */
+mr_status mr_scene_export_tree(const mr_scene *scene, float *corners6, int32_t *meta3, uint32_t *leaf_prims);
+
+/* ---- Scene::trace, batched (Scene.cpp:214-268 -> BVH.cpp:438-658 -> Triangle.cpp:136-169) ------- */
+/* stream: a hipStream_t (NULL = default stream).  Host buffers are staged synchronously;
+ * with both buffers on the device the call only enqueues work on `stream`. */
+mr_status mr_trace(mr_scene *scene, const mr_ray *rays, uint64_t n_rays, mr_hit *hits,
+                   uint32_t flags, void *stream);
+/* -DSTATS counters accumulated by MR_COUNT_STATS traces (synchronises the device) */
+mr_status mr_trace_get_stats(mr_scene *scene, uint64_t *box_tests, uint64_t *tri_tests, int32_t reset);
+
+/* ---- callers of the path, on the device ("next" rows: Camera::eyeRay, Phong shadow ray) ---------- */
+/* Camera::eyeRay (Camera.cpp:104-161) for rows [y0,y1), spp samples per pixel, ray index
+ * ((y-y0)*W+x)*spp+s.  jitter=0: pixel centres (randomize=false).  d_rays: device pointer. */
+mr_status mr_gen_eye_rays(mr_scene *scene, const mr_camera *cam, uint32_t W, uint32_t H,
+                          uint32_t y0, uint32_t y1, uint32_t spp, uint32_t jitter, uint32_t seed,
+                          mr_ray *d_rays, void *stream);
+/* Phong::shade shadow ray (Phong.cpp:80-97) for every hit, compacted with a wave64 ballot /
+ * prefix sum.  d_out needs room for n rays; d_src[k] = index of the originating ray (may be NULL);
+ * d_count: device uint64 receiving the number of shadow rays (zeroed by the call).
+ * The compacted order is wave-granular, not ray order; use d_src to match. */
+mr_status mr_gen_shadow_rays(mr_scene *scene, const mr_ray *d_rays, const mr_hit *d_hits, uint64_t n,
+                             const float light[3], mr_ray *d_out, uint32_t *d_src, uint64_t *d_count,
+                             void *stream);
+/* HitInfo::P and ::N (Triangle.cpp:160,162), device buffers of 3 floats per ray (either may be NULL) */
+mr_status mr_hit_attrs(mr_scene *scene, const mr_hit *d_hits, uint64_t n, float *d_P, float *d_N, void *stream);
+
+const char *mr_last_error(void);
+const char *mr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRO_HIP_H */

@@ -1,0 +1,45 @@
+/* miro_oracle_internal.h -- shared between the scalar and SSE halves of the oracle.
+ * TEST INFRASTRUCTURE ONLY (see miro_oracle.h). */
+#ifndef MIRO_ORACLE_INTERNAL_H
+#define MIRO_ORACLE_INTERNAL_H
+
+#include "miro_oracle.h"
+
+typedef struct { float x, y, z; } v3;
+
+/* Vector3.h:83-109,238-255 -- one rounded fp32 op per arithmetic operator */
+static inline v3 v3sub(v3 a, v3 b) { v3 r = {a.x - b.x, a.y - b.y, a.z - b.z}; return r; }
+static inline v3 v3add(v3 a, v3 b) { v3 r = {a.x + b.x, a.y + b.y, a.z + b.z}; return r; }
+static inline v3 v3scale(v3 a, float s) { v3 r = {a.x * s, a.y * s, a.z * s}; return r; }
+static inline float v3dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline v3 v3cross(v3 a, v3 b)
+{
+    v3 r = {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+    return r;
+}
+
+/* one BVH node (BVH.h:29-63): padded corners, leaf flag, children or [first,count) */
+typedef struct {
+    float c[2][3];
+    int leaf;
+    int a, b;
+    int depth;
+} orc_node;
+
+struct orc_scene {
+    int nv, nn, nt;
+    float *v, *n;            /* vertices / normals, xyz triples */
+    uint32_t *vi, *ni;       /* per-triangle vertex / normal indices */
+    v3 *omin, *omax, *ocen;  /* per-object bounds and centre */
+    orc_node *nodes;
+    int n_nodes, cap_nodes, n_leaves, max_depth, leaf_size;
+    uint32_t *leaf_prims;
+    int n_leaf_prims;
+    void *sse;               /* packet cache of the SSE path */
+};
+
+int  orc_tri_test(const orc_scene *s, uint32_t prim, const orc_ray *r, float tMin, float tMax, orc_hit *out);
+void orc_sse_prepare(orc_scene *s);
+void orc_sse_free(orc_scene *s);
+
+#endif

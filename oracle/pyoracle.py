@@ -1,0 +1,208 @@
+"""ctypes binding of oracle/libmiro_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module (see oracle/miro_oracle.h).  The product package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmiro_oracle.so")
+
+RAY_DTYPE = np.dtype([("ox", "<f4"), ("oy", "<f4"), ("oz", "<f4"), ("tmin", "<f4"),
+                      ("dx", "<f4"), ("dy", "<f4"), ("dz", "<f4"), ("tmax", "<f4")])
+HIT_DTYPE = np.dtype([("t", "<f4"), ("prim", "<u4"), ("beta", "<f4"), ("gamma", "<f4")])
+MISS = 0xFFFFFFFF
+
+
+class Camera(C.Structure):
+    _fields_ = [("eye", C.c_float * 3), ("lookat", C.c_float * 3), ("up", C.c_float * 3),
+                ("fov_deg", C.c_float)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("box_tests", C.c_uint64), ("tri_tests", C.c_uint64)]
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile).  Building the checker is not using it."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-s", "-C", HERE])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        vp, f32p, u32p, u64p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+        L.orc_scene_new.restype = vp
+        L.orc_scene_free.argtypes = [vp]
+        L.orc_scene_add_obj.argtypes = [vp, C.c_char_p, f32p]
+        L.orc_scene_add_triangle.argtypes = [vp, f32p, f32p]
+        L.orc_scene_add_arrays.argtypes = [vp, C.c_int, f32p, C.c_int, f32p, C.c_int, u32p, u32p]
+        L.orc_scene_counts.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        for name, rt in (("orc_scene_vertices", f32p), ("orc_scene_normals", f32p),
+                         ("orc_scene_vidx", u32p), ("orc_scene_nidx", u32p)):
+            getattr(L, name).argtypes = [vp]
+            getattr(L, name).restype = rt
+        L.orc_scene_build.argtypes = [vp, C.c_int]
+        L.orc_scene_tree_stats.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_scene_export_tree.argtypes = [vp, f32p, C.POINTER(C.c_int32), u32p]
+        L.orc_trace.argtypes = [vp, vp, C.c_uint64, vp, C.POINTER(Counters)]
+        L.orc_trace_brute.argtypes = [vp, vp, C.c_uint64, vp]
+        L.orc_trace_sse.argtypes = [vp, vp, C.c_uint64, vp, C.c_int, C.POINTER(Counters)]
+        L.orc_trace_sse.restype = C.c_int
+        L.orc_eye_rays.argtypes = [C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_uint32, vp]
+        L.orc_shadow_rays.argtypes = [vp, vp, vp, C.c_uint64, f32p, vp, u64p, C.c_int]
+        L.orc_shadow_rays.restype = C.c_uint64
+        L.orc_hit_attrs.argtypes = [vp, vp, C.c_uint64, f32p, f32p]
+        L.orc_hash.argtypes = [C.c_uint32]
+        L.orc_hash.restype = C.c_uint32
+        _lib = L
+    return _lib
+
+
+def _f32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _u32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def make_camera(eye, lookat, up, fov_deg):
+    cam = Camera()
+    cam.eye[:] = eye
+    cam.lookat[:] = lookat
+    cam.up[:] = up
+    cam.fov_deg = fov_deg
+    return cam
+
+
+class Scene:
+    """Reference-shaped scene: meshes appended in addObject order, then BVH::build."""
+
+    def __init__(self):
+        self.L = lib()
+        self.h = self.L.orc_scene_new()
+        self.leaf_size = None
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.orc_scene_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def add_obj(self, path, ctm=None):
+        m = None
+        if ctm is not None:
+            m = np.ascontiguousarray(ctm, dtype=np.float32).reshape(16)
+        n = self.L.orc_scene_add_obj(self.h, os.fsencode(path), _f32p(m) if m is not None else None)
+        if n < 0:
+            raise FileNotFoundError(path)
+        return n
+
+    def add_triangle(self, verts, normals):
+        v = np.ascontiguousarray(verts, dtype=np.float32).reshape(9)
+        n = np.ascontiguousarray(normals, dtype=np.float32).reshape(9)
+        return self.L.orc_scene_add_triangle(self.h, _f32p(v), _f32p(n))
+
+    def add_arrays(self, v, n, vi, ni):
+        v = np.ascontiguousarray(v, dtype=np.float32).reshape(-1, 3)
+        n = np.ascontiguousarray(n, dtype=np.float32).reshape(-1, 3)
+        vi = np.ascontiguousarray(vi, dtype=np.uint32).reshape(-1, 3)
+        ni = np.ascontiguousarray(ni, dtype=np.uint32).reshape(-1, 3)
+        return self.L.orc_scene_add_arrays(self.h, len(v), _f32p(v), len(n), _f32p(n), len(vi), _u32p(vi), _u32p(ni))
+
+    def counts(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self.L.orc_scene_counts(self.h, a, b, c)
+        return a.value, b.value, c.value
+
+    def arrays(self):
+        nv, nn, nt = self.counts()
+        v = np.ctypeslib.as_array(self.L.orc_scene_vertices(self.h), shape=(nv, 3)).copy()
+        n = np.ctypeslib.as_array(self.L.orc_scene_normals(self.h), shape=(nn, 3)).copy()
+        vi = np.ctypeslib.as_array(self.L.orc_scene_vidx(self.h), shape=(nt, 3)).copy()
+        ni = np.ctypeslib.as_array(self.L.orc_scene_nidx(self.h), shape=(nt, 3)).copy()
+        return v, n, vi, ni
+
+    def build(self, leaf_size=4):
+        self.leaf_size = leaf_size
+        return self.L.orc_scene_build(self.h, leaf_size)
+
+    def tree_stats(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self.L.orc_scene_tree_stats(self.h, a, b, c)
+        return a.value, b.value, c.value
+
+    def export_tree(self):
+        nodes, _, _ = self.tree_stats()
+        _, _, nt = self.counts()
+        corners = np.zeros((nodes, 6), np.float32)
+        meta = np.zeros((nodes, 3), np.int32)
+        prims = np.zeros(nt, np.uint32)
+        self.L.orc_scene_export_tree(self.h, _f32p(corners), meta.ctypes.data_as(C.POINTER(C.c_int32)), _u32p(prims))
+        return corners, meta, prims
+
+    def trace(self, rays, counters=False):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.empty(len(rays), HIT_DTYPE)
+        ctr = Counters(0, 0)
+        self.L.orc_trace(self.h, rays.ctypes.data, len(rays), hits.ctypes.data, C.byref(ctr))
+        if counters:
+            return hits, (ctr.box_tests, ctr.tri_tests)
+        return hits
+
+    def trace_brute(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.empty(len(rays), HIT_DTYPE)
+        self.L.orc_trace_brute(self.h, rays.ctypes.data, len(rays), hits.ctypes.data)
+        return hits
+
+    def trace_sse(self, rays, threads=0, counters=False):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.empty(len(rays), HIT_DTYPE)
+        ctr = Counters(0, 0)
+        used = self.L.orc_trace_sse(self.h, rays.ctypes.data, len(rays), hits.ctypes.data, threads, C.byref(ctr))
+        if used < 0:
+            raise RuntimeError("orc_trace_sse needs a scene built with leaf_size=8")
+        if counters:
+            return hits, used, (ctr.box_tests, ctr.tri_tests)
+        return hits, used
+
+    def shadow_rays(self, rays, hits, light, sse_order=False):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        out = np.empty(len(rays), RAY_DTYPE)
+        src = np.empty(len(rays), np.uint64)
+        l = np.ascontiguousarray(light, dtype=np.float32)
+        k = self.L.orc_shadow_rays(self.h, rays.ctypes.data, hits.ctypes.data, len(rays), _f32p(l),
+                                   out.ctypes.data, src.ctypes.data_as(C.POINTER(C.c_uint64)), 1 if sse_order else 0)
+        return out[:k].copy(), src[:k].copy()
+
+    def hit_attrs(self, hits):
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        P = np.empty((len(hits), 3), np.float32)
+        N = np.empty((len(hits), 3), np.float32)
+        self.L.orc_hit_attrs(self.h, hits.ctypes.data, len(hits), _f32p(P), _f32p(N))
+        return P, N
+
+
+def eye_rays(cam, W, H, spp=1, jitter=False, seed=168, y0=0, y1=None):
+    if y1 is None:
+        y1 = H
+    rays = np.empty((y1 - y0) * W * spp, RAY_DTYPE)
+    lib().orc_eye_rays(C.byref(cam), W, H, y0, y1, spp, 1 if jitter else 0, seed, rays.ctypes.data)
+    return rays

@@ -1,0 +1,152 @@
+"""Host logic of the product (OBJ ingestion, BVH::build) against the oracle -- no GPU needed.
+The product is built host_only here; nothing is computed by a device and nothing falls back to the CPU
+for tracing (mr_trace on a host_only scene is an error, see test_abi.py)."""
+import numpy as np
+import pytest
+
+from helpers import oracle_scene, product_scene
+from miro_amd import scenes
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("name", ["cornell", "teapot", "bunny", "sponza", "testobj", "sphere"])
+def test_loader_bit_identical(oracle, miro, name):
+    """TriangleMesh::load semantics: vertices, normals (incl. synthesised + averaged) and indices."""
+    a = oracle.Scene()
+    scenes.populate(a, name)
+    b = miro.Scene()
+    scenes.populate(b, name)
+    va, na, via, nia = a.arrays()
+    vb, nb, vib, nib = b.arrays()
+    assert va.shape == vb.shape and na.shape == nb.shape
+    assert np.array_equal(_bits(va), _bits(vb))
+    assert np.array_equal(_bits(na), _bits(nb))
+    assert np.array_equal(via, vib) and np.array_equal(nia, nib)
+
+
+def test_loader_with_transform(oracle, miro, tmp_path):
+    """ctm * v and normalise((ctm^-1)^T n) -- the makeBunny20Scene style of instancing
+    (assignment2.cpp:148-156); teapot.obj has explicit vn records."""
+    ang = np.deg2rad(25.0)
+    c, s_ = np.cos(ang), np.sin(ang)
+    ctm = np.array([[0.3 * c, -2.0 * s_, 0, -1.0], [0.3 * s_, 2.0 * c, 0, 0.4], [0, 0, 0.7, 0.3], [0, 0, 0, 1]], np.float32)
+    a = oracle.Scene()
+    a.add_obj(scenes._model("teapot.obj"), ctm)
+    b = miro.Scene()
+    b.add_obj(scenes._model("teapot.obj"), ctm)
+    for x, y in zip(a.arrays(), b.arrays()):
+        assert np.array_equal(_bits(x), _bits(y))
+
+
+def test_loader_edge_cases(oracle, miro, tmp_path):
+    """Long records are cut at 79 characters (fgets(line, 80)), v/t/n and v//n corners, comment and
+    unknown records, a face whose last corner has no normal index."""
+    p = tmp_path / "edge.obj"
+    p.write_text(
+        "# comment\n"
+        "o thing\n"
+        "v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0.5\n"
+        "v 2.000000 0.000000 0.000000                                                     9 9 9\n"
+        "vt 0 0\nvt 1 0\n"
+        "vn 0 0 2\nvn 0 3 0\n"
+        "f 1/1/1 2/2/1 3/1/2\n"
+        "f 2//1 4//2 3//2\n"
+        "f 2 5 4\n"
+        "f 1/1 2/2 4/1\n"
+        "g group\n"
+        "f 3/1/2 4/2/2 5\n"
+    )
+    a = oracle.Scene()
+    na = a.add_obj(str(p))
+    b = miro.Scene()
+    nb = b.add_obj(str(p))
+    assert na == nb == 5
+    for x, y in zip(a.arrays(), b.arrays()):
+        assert x.shape == y.shape
+        assert np.array_equal(_bits(x), _bits(y))
+
+
+def test_missing_file_is_an_error(miro):
+    s = miro.Scene()
+    with pytest.raises(miro.MiroError) as e:
+        s.add_obj("/nonexistent/model.obj")
+    assert e.value.status == -2 and "nonexistent" in str(e.value)
+
+
+@pytest.mark.parametrize("name,leaf", [("cornell", 4), ("teapot", 4), ("teapot", 8), ("bunny", 4), ("bunny", 8),
+                                       ("sponza", 4), ("sphere", 4), ("testobj", 4)])
+def test_builder_tree_identical(oracle, miro, name, leaf):
+    """BVH::build: same nodes (padded corners bit-equal), same topology, same leaf contents and order."""
+    a = oracle_scene(oracle, name, leaf)
+    b = product_scene(miro, name, leaf, host_only=True)
+    ca, ma, pa = a.export_tree()
+    cb, mb, pb = b.export_tree()
+    info = b.info()
+    assert (info.n_nodes, info.n_leaves) == a.tree_stats()[:2]
+    assert info.max_depth == a.tree_stats()[2]
+    assert np.array_equal(_bits(ca), _bits(cb))
+    assert np.array_equal(ma, mb)
+    assert np.array_equal(pa, pb)
+
+
+def test_builder_known_answers(miro):
+    """Stats::BVH_Nodes / BVH_LeafNodes of the reference (Readme.tex:95-96)."""
+    for name, leaf, want in (("teapot", 4, (385, 193)), ("teapot", 8, (199, 100)),
+                             ("bunny", 4, (42881, 21441)), ("bunny", 8, (23203, 11602))):
+        i = product_scene(miro, name, leaf, host_only=True).info()
+        assert (i.n_nodes, i.n_leaves) == want
+
+
+def test_builder_degenerate_inputs(oracle, miro):
+    """Empty scene, one triangle, coincident centroids (forces the depth-32 cut-off and leaves with more
+    than 15 triangles), a flat grid (zero-volume boxes)."""
+    tri_v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    tri_n = np.array([[0, 0, 1]] * 3, np.float32)
+    cases = []
+    cases.append((np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32)))
+    cases.append((tri_v, tri_n, np.array([[0, 1, 2]], np.uint32)))
+    # 40 triangles sharing one centroid: every split puts all of them on one side
+    # (identical vertex triples: the rounded centroids are bit-equal, so no plane ever separates them)
+    vs, fs = [], []
+    for k in range(40):
+        vs += [[0.25, 0.5, -1.0], [1.5, 0.125, 0.75], [-0.5, 2.0, 0.5]]
+        fs.append([3 * k, 3 * k + 1, 3 * k + 2])
+    cases.append((np.array(vs, np.float32), np.tile(np.array([[0, 0, 1]], np.float32), (len(vs), 1)), np.array(fs, np.uint32)))
+    # flat 12x12 grid in the plane y = 0
+    g = np.array([[x, 0, z] for x in range(13) for z in range(13)], np.float32)
+    f = []
+    for x in range(12):
+        for z in range(12):
+            a0 = x * 13 + z
+            f += [[a0, a0 + 13, a0 + 14], [a0, a0 + 14, a0 + 1]]
+    cases.append((g, np.tile(np.array([[0, 1, 0]], np.float32), (len(g), 1)), np.array(f, np.uint32)))
+    for v, n, f in cases:
+        a = oracle.Scene()
+        b = miro.Scene()
+        if len(f):
+            a.add_arrays(v, n, f, f)
+            b.add_arrays(v, n, f, f)
+        a.build(4)
+        b.build(4, host_only=True)
+        ca, ma, pa = a.export_tree()
+        cb, mb, pb = b.export_tree()
+        assert np.array_equal(_bits(ca), _bits(cb)) and np.array_equal(ma, mb) and np.array_equal(pa, pb)
+    # the coincident-centroid case really reaches the depth cut-off
+    a = oracle.Scene()
+    v, n, f = cases[2]
+    a.add_arrays(v, n, f, f)
+    a.build(4)
+    assert a.tree_stats()[2] == 32
+
+
+def test_atrium_standin_is_deterministic(tmp_path):
+    v1, f1 = scenes.atrium_mesh()
+    v2, f2 = scenes.atrium_mesh()
+    assert np.array_equal(v1, v2) and np.array_equal(f1, f2)
+    assert 60000 <= len(f1) <= 72000          # "~66k triangles" like the missing sponza.obj
+    p = scenes.sponza_path(str(tmp_path))
+    q = scenes.sponza_path(str(tmp_path))
+    assert p == q and open(p).read(2) == "# "
