@@ -41,6 +41,9 @@ void release_device(mr_scene *s) {
     (void)hipFree(s->d_stage_rays); (void)hipFree(s->d_stage_hits);
     s->d_stage_rays = s->d_stage_hits = nullptr;
     s->stage_cap = 0;
+    (void)hipFree(s->d_occluded);
+    s->d_occluded = nullptr;
+    s->occluded_cap = 0;
 }
 
 inline int32_t leaf_ref(uint32_t first, uint32_t count) {
@@ -315,7 +318,7 @@ mr_status mr_trace(mr_scene *s, const mr_ray *rays, uint64_t n, mr_hit *hits, ui
     memcpy(p.root_hi, s->dev.root_hi, sizeof(p.root_hi));
     p.root_ref = s->dev.root_ref;
     p.stack_depth = (int32_t)s->dev.stack_depth;
-    p.rays = d_rays; p.hits = d_hits; p.n = n; p.stats = s->d_stats;
+    p.rays = d_rays; p.hits = d_hits; p.n = n; p.n_dev = nullptr; p.stats = s->d_stats;
     if ((st = launch_trace(p, flags, stream)) != MR_OK) return st;
     if (!hits_dev) {
         MR_HIP_CHECK(hipMemcpyAsync(hits, d_hits, n * sizeof(mr_hit), hipMemcpyDeviceToHost, stream));
@@ -324,6 +327,28 @@ mr_status mr_trace(mr_scene *s, const mr_ray *rays, uint64_t n, mr_hit *hits, ui
         MR_HIP_CHECK(hipStreamSynchronize(stream));   // the staged host rays may be reused by the caller
     }
     return MR_OK;
+}
+
+mr_status mr_trace_indirect(mr_scene *s, const mr_ray *d_rays, const uint64_t *d_count, uint64_t max_rays,
+                            mr_hit *d_hits, uint32_t flags, void *stream_v) {
+    mr_status st = require_device(s);
+    if (st != MR_OK) return st;
+    if (max_rays == 0) return MR_OK;
+    if (!d_rays || !d_hits || !d_count) return fail(MR_ERR_INVALID, "NULL argument");
+    if ((reinterpret_cast<uintptr_t>(d_rays) & 15) || (reinterpret_cast<uintptr_t>(d_hits) & 15) ||
+        (reinterpret_cast<uintptr_t>(d_count) & 7))
+        return fail(MR_ERR_INVALID, "device ray/hit buffers must be 16-byte aligned, the count 8-byte aligned");
+    MR_HIP_CHECK(hipSetDevice(s->device));
+    TraceParams p;
+    p.nodes = s->dev.nodes; p.tris = s->dev.tris; p.tri_prim = s->dev.tri_prim; p.leaf_cnt_ext = s->dev.leaf_cnt_ext;
+    memcpy(p.root_lo, s->dev.root_lo, sizeof(p.root_lo));
+    memcpy(p.root_hi, s->dev.root_hi, sizeof(p.root_hi));
+    p.root_ref = s->dev.root_ref;
+    p.stack_depth = (int32_t)s->dev.stack_depth;
+    p.rays = d_rays; p.hits = d_hits; p.n = max_rays;
+    p.n_dev = reinterpret_cast<const unsigned long long *>(d_count);
+    p.stats = s->d_stats;
+    return launch_trace(p, flags, static_cast<hipStream_t>(stream_v));
 }
 
 mr_status mr_trace_get_stats(mr_scene *s, uint64_t *box_tests, uint64_t *tri_tests, int32_t reset) {
@@ -357,6 +382,33 @@ mr_status mr_gen_shadow_rays(mr_scene *s, const mr_ray *d_rays, const mr_hit *d_
     MR_HIP_CHECK(hipSetDevice(s->device));
     return launch_shadow_rays(s->dev, d_rays, d_hits, n, light, d_out, d_src,
                               reinterpret_cast<unsigned long long *>(d_count), static_cast<hipStream_t>(stream));
+}
+
+mr_status mr_shade_direct(mr_scene *s, const mr_ray *d_rays, const mr_hit *d_hits, uint64_t n, const mr_hit *d_shadow_hits,
+                          const uint32_t *d_shadow_src, const uint64_t *d_shadow_count, const mr_light *light,
+                          const float diffuse[3], uint32_t spp, float *d_rgb, void *stream) {
+    mr_status st = require_device(s);
+    if (st != MR_OK) return st;
+    if (!d_rays || !d_hits || !d_shadow_hits || !d_shadow_src || !d_shadow_count || !light || !diffuse || !d_rgb)
+        return fail(MR_ERR_INVALID, "NULL argument");
+    if (spp == 0 || n % spp != 0) return fail(MR_ERR_INVALID, "n (%llu) must be a multiple of spp (%u)", (unsigned long long)n, spp);
+    MR_HIP_CHECK(hipSetDevice(s->device));
+    if (n > s->occluded_cap) {     // grow-only scratch; size it with a first call outside any graph capture
+        (void)hipFree(s->d_occluded);
+        s->d_occluded = nullptr;
+        s->occluded_cap = 0;
+        MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&s->d_occluded), n));
+        s->occluded_cap = n;
+    }
+    return launch_shade(s->dev, d_rays, d_hits, n, d_shadow_hits, d_shadow_src,
+                        reinterpret_cast<const unsigned long long *>(d_shadow_count), s->d_occluded, *light, diffuse, spp,
+                        d_rgb, static_cast<hipStream_t>(stream));
+}
+
+mr_status mr_tonemap(mr_scene *s, const float *d_rgb, uint64_t n_values, uint8_t *d_out, void *stream) {
+    if (!s || !d_rgb || !d_out) return fail(MR_ERR_INVALID, "NULL argument");
+    MR_HIP_CHECK(hipSetDevice(s->device));
+    return launch_tonemap(d_rgb, n_values, d_out, static_cast<hipStream_t>(stream));
 }
 
 mr_status mr_hit_attrs(mr_scene *s, const mr_hit *d_hits, uint64_t n, float *d_P, float *d_N, void *stream) {

@@ -91,7 +91,8 @@ struct TraceParams {
     int32_t stack_depth;
     const mr_ray *rays;
     mr_hit *hits;
-    unsigned long long n;
+    unsigned long long n;                 // number of rays (upper bound when n_dev is set)
+    const unsigned long long *n_dev;      // optional device-resident ray count (mr_trace_indirect)
     unsigned long long *stats;   // [0] box tests, [1] triangle tests (MR_COUNT_STATS)
 };
 
@@ -103,6 +104,12 @@ mr_status launch_shadow_rays(const DeviceScene &ds, const mr_ray *d_rays, const 
                              unsigned long long *d_count, hipStream_t stream);
 mr_status launch_hit_attrs(const DeviceScene &ds, const mr_hit *d_hits, unsigned long long n,
                            float *d_P, float *d_N, hipStream_t stream);
+
+mr_status launch_shade(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits, unsigned long long n,
+                       const mr_hit *d_shadow_hits, const uint32_t *d_shadow_src, const unsigned long long *d_shadow_count,
+                       uint8_t *d_occluded, const mr_light &light, const float diffuse[3], uint32_t spp, float *d_rgb,
+                       hipStream_t stream);
+mr_status launch_tonemap(const float *d_rgb, unsigned long long n_values, uint8_t *d_out, hipStream_t stream);
 
 }  // namespace mr
 
@@ -117,4 +124,7 @@ struct mr_scene {
     // grow-only staging buffers for host-pointer traces
     void *d_stage_rays = nullptr, *d_stage_hits = nullptr;
     uint64_t stage_cap = 0;
+    // grow-only per-primary-ray occlusion flags for mr_shade_direct
+    uint8_t *d_occluded = nullptr;
+    uint64_t occluded_cap = 0;
 };

@@ -102,7 +102,11 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(TraceParams p) {
     const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
     Stats st = {0ull, 0ull};
 
-    for (unsigned long long idx = (unsigned long long)blockIdx.x * kBlock + tid; idx < p.n; idx += stride) {
+    // indirect batches: the ray count lives on the device (e.g. written by the shadow-ray compaction)
+    unsigned long long n_rays = p.n;
+    if (p.n_dev) { const unsigned long long nd = *p.n_dev; if (nd < n_rays) n_rays = nd; }
+
+    for (unsigned long long idx = (unsigned long long)blockIdx.x * kBlock + tid; idx < n_rays; idx += stride) {
         // two dwordx4 loads per lane, 32-byte stride: every byte of the fetched lines is used
         const float4 ra = reinterpret_cast<const float4 *>(p.rays)[2 * idx];
         const float4 rb = reinterpret_cast<const float4 *>(p.rays)[2 * idx + 1];
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void eye_rays_kernel(EyeFrame f, mr_ray *ra
         float ddx = (up * f.u[0] + vp * f.v[0]) - f.w[0];
         float ddy = (up * f.u[1] + vp * f.v[1]) - f.w[1];
         float ddz = (up * f.u[2] + vp * f.v[2]) - f.w[2];
-        const float len = __fsqrt_rn((ddx * ddx + ddy * ddy) + ddz * ddz);
+        const float len = sqrtf((ddx * ddx + ddy * ddy) + ddz * ddz);
         const float inv = 1.0f / len;
         float4 a = make_float4(f.eye[0], f.eye[1], f.eye[2], 0.0f);
         float4 b = make_float4(ddx * inv, ddy * inv, ddz * inv, 1e12f);     // MIRO_TMAX
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(kBlock) void shadow_rays_kernel(MeshPtrs m, const m
             hit_point(m, __float_as_uint(h.y), h.z, h.w, Px, Py, Pz);
             float lx = Lx - Px, ly = Ly - Py, lz = Lz - Pz;           // PointLight::getLightDirection
             const float falloff = (lx * lx + ly * ly) + lz * lz;
-            const float len = __fsqrt_rn(falloff);
+            const float len = sqrtf(falloff);
             const float inv = 1.0f / len;                              // l /= sqrt(falloff)
             lx *= inv; ly *= inv; lz *= inv;
             float4 a = make_float4(Px + lx * kEps, Py + ly * kEps, Pz + lz * kEps, 0.0f);

@@ -1,0 +1,152 @@
+// mr_shade.hip -- the caller of the shadow batch, on the device ("next" row f2 of SURVEY.md section 8):
+//   occlusion scatter   shadow hits -> one flag per primary ray (Phong.cpp:97-100, opaque occluders)
+//   shade_pixels        Phong::shade for one point light and a uniform Lambert/Phong material
+//                       (Phong.cpp:44-160), Scene::trace's normal normalisation (Scene.cpp:262),
+//                       the miss colour (Scene.cpp:340,685) and the per-pixel sample average
+//                       (Scene.cpp:126-139) into a linear float RGB buffer (tempImage, Scene.cpp:106)
+//   tonemap             sigmoid(6v-3) and the 8-bit mapping (Scene.cpp:87-91,177-202; Image.cpp:44-50)
+// Floating point here is tolerance-parity (powf, expf differ from libm in the last ulps); the hot
+// path's bit-exactness is unaffected.
+#include <hip/hip_runtime.h>
+
+#include "mr_internal.h"
+
+namespace mr {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr float kPI = 3.1415926535897932384626433832795028841972f;   // Miro.h:10
+
+__global__ __launch_bounds__(kBlock) void occlusion_scatter_kernel(const mr_hit *shadow_hits, const uint32_t *src,
+                                                                   const unsigned long long *count,
+                                                                   unsigned long long max_n, uint8_t *occluded) {
+    unsigned long long n = *count;
+    if (n > max_n) n = max_n;
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; k < n; k += stride)
+        occluded[src[k]] = shadow_hits[k].prim != MR_MISS ? 1 : 0;
+}
+
+struct ShadeArgs {
+    const float *v, *n;
+    const uint32_t *vi, *ni;
+    const mr_ray *rays;
+    const mr_hit *hits;
+    const uint8_t *occluded;
+    float L[3], color[3], diffuse[3], bg[3];
+    float wattage;
+    uint32_t spp;
+    unsigned long long n_pixels;
+    float *rgb;
+};
+
+__device__ __forceinline__ void shade_sample(const ShadeArgs &a, unsigned long long k, float out[3]) {
+    const float4 h = reinterpret_cast<const float4 *>(a.hits)[k];
+    const uint32_t prim = __float_as_uint(h.y);
+    if (prim == MR_MISS) { out[0] = a.bg[0]; out[1] = a.bg[1]; out[2] = a.bg[2]; return; }   // Scene.cpp:340
+    out[0] = out[1] = out[2] = 0.0f;
+    if (a.occluded[k]) return;                                                              // Phong.cpp:97-100
+    const float beta = h.z, gamma = h.w;
+    const size_t t3 = 3 * (size_t)prim;
+    const uint32_t ia = a.vi[t3], ib = a.vi[t3 + 1], ic = a.vi[t3 + 2];
+    const uint32_t ja = a.ni[t3], jb = a.ni[t3 + 1], jc = a.ni[t3 + 2];
+    float P[3], N[3];
+    const float alpha = 1 - beta - gamma;
+    for (int c = 0; c < 3; c++) {
+        const float A = a.v[3 * (size_t)ia + c];
+        const float BmA = a.v[3 * (size_t)ib + c] - A, CmA = a.v[3 * (size_t)ic + c] - A;
+        P[c] = (A + beta * BmA) + gamma * CmA;                                               // Triangle.cpp:160
+        N[c] = (alpha * a.n[3 * (size_t)ja + c] + beta * a.n[3 * (size_t)jb + c]) + gamma * a.n[3 * (size_t)jc + c];
+    }
+    {   // Scene.cpp:262 -- N.normalize()
+        const float inv = 1.0f / sqrtf((N[0] * N[0] + N[1] * N[1]) + N[2] * N[2]);
+        N[0] *= inv; N[1] *= inv; N[2] *= inv;
+    }
+    float l[3] = {a.L[0] - P[0], a.L[1] - P[1], a.L[2] - P[2]};
+    const float falloff = (l[0] * l[0] + l[1] * l[1]) + l[2] * l[2];
+    {
+        const float inv = 1.0f / sqrtf(falloff);
+        l[0] *= inv; l[1] *= inv; l[2] *= inv;
+    }
+    const float nDotL = (N[0] * l[0] + N[1] * l[1]) + N[2] * l[2];
+    const float f2 = 1.0f / (falloff * 4.0f * kPI * kPI);                                   // Phong.cpp:140
+    const float diff = fmaxf(0.0f, nDotL * f2 * a.wattage);
+    for (int c = 0; c < 3; c++) out[c] = a.color[c] * (diff * a.diffuse[c] * a.diffuse[c]);  // :146
+    // specular highlight (:149-156); Phong's default shininess 1 < infinity
+    const float lDotN = (l[0] * N[0] + l[1] * N[1]) + l[2] * N[2];
+    const float4 rb = reinterpret_cast<const float4 *>(a.rays)[2 * k + 1];
+    float eDotr = 0.0f;
+    {
+        const float two = 2 * lDotN;
+        const float rx = -l[0] + two * N[0], ry = -l[1] + two * N[1], rz = -l[2] + two * N[2];
+        eDotr = (-rb.x * rx + -rb.y * ry) + -rb.z * rz;
+    }
+    eDotr = powf(fmaxf(0.0f, fminf(1.0f, eDotr)), 500.0f);
+    const float highlights = fmaxf(0.0f, eDotr * f2 * a.wattage);
+    out[0] += highlights; out[1] += highlights; out[2] += highlights;
+}
+
+// one thread per pixel, samples summed in order (bitwise reproducible, independent of the grid)
+__global__ __launch_bounds__(kBlock) void shade_pixels_kernel(ShadeArgs a) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
+    const float inv_spp = 1.0f / (float)a.spp;
+    for (unsigned long long pix = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; pix < a.n_pixels; pix += stride) {
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (uint32_t s = 0; s < a.spp; s++) {
+            float c[3];
+            shade_sample(a, pix * a.spp + s, c);
+            acc[0] += c[0]; acc[1] += c[1]; acc[2] += c[2];
+        }
+        if (a.spp > 1) { acc[0] *= inv_spp; acc[1] *= inv_spp; acc[2] *= inv_spp; }          // Scene.cpp:139
+        a.rgb[3 * pix] = acc[0]; a.rgb[3 * pix + 1] = acc[1]; a.rgb[3 * pix + 2] = acc[2];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void tonemap_kernel(const float *rgb, unsigned long long n_values, uint8_t *out) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < n_values; i += stride) {
+        float v = rgb[i];
+        v = 1.0f / (1.0f + expf(-(6.0f * v - 3.0f)));               // sigmoid(6v-3), Scene.cpp:89, Utility.h:19-22
+        const float m = 255.0f * v;                                 // Image.cpp:44-50
+        out[i] = m > 255.0f ? 255 : (uint8_t)m;
+    }
+}
+
+inline unsigned grid_for(unsigned long long n) {
+    unsigned long long blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > 256ull * 32ull) blocks = 256ull * 32ull;
+    if (blocks == 0) blocks = 1;
+    return (unsigned)blocks;
+}
+
+}  // namespace
+
+mr_status launch_shade(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits, unsigned long long n,
+                       const mr_hit *d_shadow_hits, const uint32_t *d_shadow_src, const unsigned long long *d_shadow_count,
+                       uint8_t *d_occluded, const mr_light &light, const float diffuse[3], uint32_t spp, float *d_rgb,
+                       hipStream_t stream) {
+    if (n == 0) return MR_OK;
+    hipLaunchKernelGGL(occlusion_scatter_kernel, dim3(grid_for(n)), dim3(kBlock), 0, stream, d_shadow_hits, d_shadow_src,
+                       d_shadow_count, n, d_occluded);
+    MR_HIP_CHECK(hipGetLastError());
+    ShadeArgs a;
+    a.v = ds.v; a.n = ds.n; a.vi = ds.vi; a.ni = ds.ni;
+    a.rays = d_rays; a.hits = d_hits; a.occluded = d_occluded;
+    for (int c = 0; c < 3; c++) { a.L[c] = light.position[c]; a.color[c] = light.color[c]; a.diffuse[c] = diffuse[c]; a.bg[c] = 0.0f; }
+    a.wattage = light.wattage;
+    a.spp = spp;
+    a.n_pixels = n / spp;
+    a.rgb = d_rgb;
+    hipLaunchKernelGGL(shade_pixels_kernel, dim3(grid_for(a.n_pixels)), dim3(kBlock), 0, stream, a);
+    MR_HIP_CHECK(hipGetLastError());
+    return MR_OK;
+}
+
+mr_status launch_tonemap(const float *d_rgb, unsigned long long n_values, uint8_t *d_out, hipStream_t stream) {
+    if (n_values == 0) return MR_OK;
+    hipLaunchKernelGGL(tonemap_kernel, dim3(grid_for(n_values)), dim3(kBlock), 0, stream, d_rgb, n_values, d_out);
+    MR_HIP_CHECK(hipGetLastError());
+    return MR_OK;
+}
+
+}  // namespace mr

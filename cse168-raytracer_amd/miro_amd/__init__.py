@@ -12,3 +12,4 @@ from .binding import (  # noqa: F401
     EXPORTED_SYMBOLS,
 )
 from . import scenes  # noqa: F401
+from . import frame  # noqa: F401

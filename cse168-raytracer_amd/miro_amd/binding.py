@@ -26,7 +26,8 @@ MR_OK, MR_ERR_INVALID, MR_ERR_IO, MR_ERR_NOMEM, MR_ERR_HIP, MR_ERR_STATE = 0, -1
 EXPORTED_SYMBOLS = [
     "mr_scene_create", "mr_scene_destroy", "mr_scene_add_mesh", "mr_scene_add_obj", "mr_scene_add_triangle",
     "mr_bvh_build", "mr_scene_get_info", "mr_scene_get_mesh", "mr_scene_export_tree",
-    "mr_trace", "mr_trace_get_stats", "mr_gen_eye_rays", "mr_gen_shadow_rays", "mr_hit_attrs",
+    "mr_trace", "mr_trace_indirect", "mr_trace_get_stats", "mr_gen_eye_rays", "mr_gen_shadow_rays", "mr_hit_attrs",
+    "mr_shade_direct", "mr_tonemap",
     "mr_last_error", "mr_version",
 ]
 
@@ -61,16 +62,8 @@ class Camera(C.Structure):
                 ("fov_deg", C.c_float)]
 
 
-class FrameDesc(C.Structure):
-    _fields_ = [("cam", Camera), ("light", C.c_float * 3), ("W", C.c_uint32), ("H", C.c_uint32),
-                ("y0", C.c_uint32), ("y1", C.c_uint32), ("spp", C.c_uint32), ("jitter", C.c_uint32),
-                ("seed", C.c_uint32), ("flags", C.c_uint32), ("wattage", C.c_float),
-                ("reserved", C.c_uint32 * 3)]
-
-
-class FrameStats(C.Structure):
-    _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("primary_hits", C.c_uint64),
-                ("occluded", C.c_uint64)]
+class Light(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("color", C.c_float * 3), ("wattage", C.c_float)]
 
 
 def lib_path():
@@ -105,13 +98,14 @@ def load_library(path=None):
     L.mr_scene_get_mesh.argtypes = [vp, C.POINTER(MeshDesc)]
     L.mr_scene_export_tree.argtypes = [vp, f32p, C.POINTER(C.c_int32), u32p]
     L.mr_trace.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp]
+    L.mr_trace_indirect.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_uint32, vp]
     L.mr_trace_get_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]
     L.mr_gen_eye_rays.argtypes = [vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                   C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     L.mr_gen_shadow_rays.argtypes = [vp, vp, vp, C.c_uint64, f32p, vp, vp, vp, vp]
     L.mr_hit_attrs.argtypes = [vp, vp, C.c_uint64, vp, vp, vp]
-    if hasattr(L, "mr_render_frame"):
-        L.mr_render_frame.argtypes = [vp, C.POINTER(FrameDesc), vp, vp, C.POINTER(FrameStats), vp]
+    L.mr_shade_direct.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, vp, C.POINTER(Light), f32p, C.c_uint32, vp, vp]
+    L.mr_tonemap.argtypes = [vp, vp, C.c_uint64, vp, vp]
     for name in EXPORTED_SYMBOLS:
         if hasattr(L, name) and getattr(L, name).restype is C.c_int:
             getattr(L, name).restype = C.c_int32
@@ -244,6 +238,11 @@ class Scene:
         hp = d_hits.data_ptr() if hasattr(d_hits, "data_ptr") else int(d_hits)
         _check(self.L.mr_trace(self.h, rp, n, hp, flags | MR_RAYS_ON_DEVICE | MR_HITS_ON_DEVICE, _stream_ptr(stream)))
 
+    def trace_indirect(self, d_rays, d_count, max_rays, d_hits, flags=0, stream=None):
+        """Batch size read on the device from d_count (uint64/int64 tensor written by gen_shadow_rays)."""
+        _check(self.L.mr_trace_indirect(self.h, d_rays.data_ptr(), d_count.data_ptr(), max_rays, d_hits.data_ptr(),
+                                        flags, _stream_ptr(stream)))
+
     def stats(self, reset=True):
         a, b = C.c_uint64(0), C.c_uint64(0)
         _check(self.L.mr_trace_get_stats(self.h, C.byref(a), C.byref(b), 1 if reset else 0))
@@ -266,8 +265,16 @@ class Scene:
         _check(self.L.mr_hit_attrs(self.h, d_hits.data_ptr(), n, d_P.data_ptr() if d_P is not None else None,
                                    d_N.data_ptr() if d_N is not None else None, _stream_ptr(stream)))
 
-    def render_frame(self, frame, d_image, d_work, stream=None):
-        st = FrameStats()
-        _check(self.L.mr_render_frame(self.h, C.byref(frame), d_image.data_ptr(),
-                                      d_work.data_ptr() if d_work is not None else None, C.byref(st), _stream_ptr(stream)))
-        return st
+    def shade_direct(self, d_rays, d_hits, n, d_shadow_hits, d_shadow_src, d_shadow_count, light_pos, wattage,
+                     d_rgb, spp=1, color=(1.0, 1.0, 1.0), diffuse=(1.0, 1.0, 1.0), stream=None):
+        lt = Light()
+        lt.position[:] = light_pos
+        lt.color[:] = color
+        lt.wattage = wattage
+        df = np.ascontiguousarray(diffuse, dtype=np.float32)
+        _check(self.L.mr_shade_direct(self.h, d_rays.data_ptr(), d_hits.data_ptr(), n, d_shadow_hits.data_ptr(),
+                                      d_shadow_src.data_ptr(), d_shadow_count.data_ptr(), C.byref(lt), _f32p(df), spp,
+                                      d_rgb.data_ptr(), _stream_ptr(stream)))
+
+    def tonemap(self, d_rgb, n_values, d_out, stream=None):
+        _check(self.L.mr_tonemap(self.h, d_rgb.data_ptr(), n_values, d_out.data_ptr(), _stream_ptr(stream)))

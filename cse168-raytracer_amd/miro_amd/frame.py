@@ -1,0 +1,120 @@
+"""Wavefront frame driver over the C ABI: eye rays -> mr_trace -> shadow rays (ballot compaction) ->
+mr_trace_indirect -> Phong shade, for a set of image rows; plus the image-tile sharding and the single
+framebuffer gather used on a multi-GPU node.
+
+This replaces the reference's per-pixel recursion (Scene::raytraceImage, Scene.cpp:93-212) by batches;
+torch supplies device memory, streams and torch.distributed (backend "nccl" = RCCL) only.
+"""
+import numpy as np
+import torch
+
+from . import binding, scenes
+
+
+# ------------------------------------------------------------------------------------------------ sharding
+def band_rows(H, band, rank, world):
+    """Image rows owned by `rank`: horizontal bands of `band` rows dealt round-robin (interleaved for load
+    balance, cf. the reference's `schedule(dynamic, 2)` rows, Scene.cpp:113).  Returns [(y0, y1), ...]."""
+    out = []
+    nb = (H + band - 1) // band
+    for b in range(rank, nb, world):
+        out.append((b * band, min(H, (b + 1) * band)))
+    return out
+
+
+def rows_of(bands):
+    if not bands:
+        return np.zeros(0, np.int64)
+    return np.concatenate([np.arange(y0, y1, dtype=np.int64) for y0, y1 in bands])
+
+
+def gather_framebuffer(local_rgb, H, W, band, rank, world, group=None, dst=0):
+    """The one collective of a frame: every rank contributes the rows it rendered ([n_local_rows*W, 3] floats,
+    rows in band order); rank `dst` receives them in one gather and de-interleaves into [H, W, 3].
+    Contributions are padded to the largest shard so that a single fixed-size gather suffices."""
+    import torch.distributed as dist
+    counts = [sum(y1 - y0 for y0, y1 in band_rows(H, band, r, world)) for r in range(world)]
+    max_rows = max(counts)
+    send = torch.zeros((max_rows * W, 3), dtype=local_rgb.dtype, device=local_rgb.device)
+    send[:counts[rank] * W] = local_rgb.reshape(-1, 3)[:counts[rank] * W]
+    if world == 1:
+        recv = [send]
+    else:
+        recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+        dist.gather(send, recv, dst=dst, group=group)
+    if rank != dst:
+        return None
+    full = torch.empty((H, W, 3), dtype=local_rgb.dtype, device=local_rgb.device)
+    for r in range(world):
+        rows = torch.from_numpy(rows_of(band_rows(H, band, r, world))).to(full.device)
+        if len(rows):
+            full[rows] = recv[r][:counts[r] * W].reshape(counts[r], W, 3)
+    return full
+
+
+# ------------------------------------------------------------------------------------------------ renderer
+class FrameRenderer:
+    """All device buffers of one rank's share of a frame, resident for the lifetime of the object."""
+
+    def __init__(self, scene, desc, W, H, spp=1, bands=None, jitter=None, seed=168, flags=0, device=None):
+        if isinstance(desc, str):
+            desc = scenes.SCENES[desc]
+        self.scene, self.desc, self.W, self.H, self.spp = scene, desc, W, H, spp
+        self.bands = bands if bands is not None else [(0, H)]
+        self.jitter = (spp > 1) if jitter is None else jitter
+        self.seed, self.flags = seed, flags
+        self.device = torch.device("cuda", scene.device) if device is None else device
+        self.n_rows = sum(y1 - y0 for y0, y1 in self.bands)
+        self.n_pixels = self.n_rows * W
+        self.n = self.n_pixels * spp
+        n = max(self.n, 1)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.d_rays = torch.empty((n, 8), **f32)
+        self.d_hits = torch.empty((n, 4), **f32)
+        self.d_shadow_rays = torch.empty((n, 8), **f32)
+        self.d_shadow_hits = torch.empty((n, 4), **f32)
+        self.d_src = torch.empty(n, dtype=torch.int32, device=self.device)
+        self.d_count = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.d_rgb = torch.zeros((max(self.n_pixels, 1), 3), **f32)
+        self.cam = binding.make_camera(desc["eye"], desc["lookat"], desc["up"], desc["fov"])
+
+    def bytes_resident(self):
+        return sum(t.numel() * t.element_size() for t in (self.d_rays, self.d_hits, self.d_shadow_rays,
+                                                          self.d_shadow_hits, self.d_src, self.d_count, self.d_rgb))
+
+    def generate(self, stream=None):
+        """Camera::eyeRay for every owned row; the rays then stay resident in HBM."""
+        off = 0
+        for y0, y1 in self.bands:
+            k = (y1 - y0) * self.W * self.spp
+            self.scene.gen_eye_rays(self.cam, self.W, self.H, self.d_rays[off:off + k], y0=y0, y1=y1, spp=self.spp,
+                                    jitter=self.jitter, seed=self.seed, stream=stream)
+            off += k
+
+    def trace_primary(self, stream=None):
+        self.scene.trace_device(self.d_rays, self.n, self.d_hits, self.flags, stream=stream)
+
+    def make_shadow_rays(self, stream=None):
+        self.scene.gen_shadow_rays(self.d_rays, self.d_hits, self.n, self.desc["light"], self.d_shadow_rays, self.d_src,
+                                   self.d_count, stream=stream)
+
+    def trace_shadow(self, stream=None, any_hit=False):
+        fl = self.flags | (binding.MR_TRACE_ANY if any_hit else 0)
+        self.scene.trace_indirect(self.d_shadow_rays, self.d_count, self.n, self.d_shadow_hits, fl, stream=stream)
+
+    def shade(self, stream=None):
+        self.scene.shade_direct(self.d_rays, self.d_hits, self.n, self.d_shadow_hits, self.d_src, self.d_count,
+                                self.desc["light"], self.desc["wattage"], self.d_rgb, spp=self.spp, stream=stream)
+
+    def step(self, stream=None, any_hit=False):
+        """One pass of the hot path over this rank's resident rays: primary batch, shadow batch, shade."""
+        if self.n == 0:
+            return
+        self.trace_primary(stream)
+        self.make_shadow_rays(stream)
+        self.trace_shadow(stream, any_hit)
+        self.shade(stream)
+
+    def ray_counts(self):
+        """(primary, shadow) of the last step -- synchronises."""
+        return self.n, int(self.d_count.item()) if self.n else 0

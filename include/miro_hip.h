@@ -84,8 +84,10 @@ enum {
                                       scene has no refractive material (Phong.cpp:99-113) */
     MR_RAYS_ON_DEVICE = 1u << 1,   /* rays is a device pointer */
     MR_HITS_ON_DEVICE = 1u << 2,   /* hits is a device pointer */
-    MR_MATH_FAST      = 1u << 3,   /* fused multiply-add + v_rcp_f32 (within 1e-5 rel. of the reference);
-                                      default is the bit-exact IEEE expression tree of Triangle.cpp:150-156 */
+    MR_MATH_FAST      = 1u << 3,   /* fused multiply-add + v_rcp_f32: same primitive, t within 1e-5 relative of the
+                                      reference, beta/gamma only within the formula's own rounding sensitivity
+                                      (~|o-A|/|edge| ulps).  The default is the bit-exact IEEE expression tree
+                                      of Triangle.cpp:150-156 and is what parity and the bench are quoted on */
     MR_COUNT_STATS    = 1u << 4    /* accumulate -DSTATS counters (BVH.cpp:461,496,632,643) */
 };
 
@@ -116,6 +118,11 @@ mr_status mr_scene_export_tree(const mr_scene *scene, float *corners6, int32_t *
  * with both buffers on the device the call only enqueues work on `stream`. */
 mr_status mr_trace(mr_scene *scene, const mr_ray *rays, uint64_t n_rays, mr_hit *hits,
                    uint32_t flags, void *stream);
+/* Same, for a batch whose size was produced on the device (the compacted shadow batch of
+ * mr_gen_shadow_rays): traces min(*d_count, max_rays) rays without a host round trip.  All pointers are
+ * device pointers; MR_RAYS_ON_DEVICE / MR_HITS_ON_DEVICE are implied. */
+mr_status mr_trace_indirect(mr_scene *scene, const mr_ray *d_rays, const uint64_t *d_count, uint64_t max_rays,
+                            mr_hit *d_hits, uint32_t flags, void *stream);
 /* -DSTATS counters accumulated by MR_COUNT_STATS traces (synchronises the device) */
 mr_status mr_trace_get_stats(mr_scene *scene, uint64_t *box_tests, uint64_t *tri_tests, int32_t reset);
 
@@ -134,6 +141,22 @@ mr_status mr_gen_shadow_rays(mr_scene *scene, const mr_ray *d_rays, const mr_hit
                              void *stream);
 /* HitInfo::P and ::N (Triangle.cpp:160,162), device buffers of 3 floats per ray (either may be NULL) */
 mr_status mr_hit_attrs(mr_scene *scene, const mr_hit *d_hits, uint64_t n, float *d_P, float *d_N, void *stream);
+
+/* ---- Phong::shade for one point light over a traced frame ("next" row: the consumer of the shadow batch) --- */
+typedef struct mr_light {                             /* PointLight.h:8-59 */
+    float position[3], color[3], wattage;
+} mr_light;
+/* For n primary rays (spp consecutive rays per pixel) with their hits, and the traced shadow batch of
+ * mr_gen_shadow_rays (hits + source indices + device count): direct lighting of a uniform material with
+ * diffuse colour `diffuse` as Phong::shade computes it (Phong.cpp:44-160; opaque occluders), normals
+ * normalised as Scene::trace does (Scene.cpp:262), misses = background 0 (Scene.cpp:340,685), averaged over
+ * the spp samples of each pixel (Scene.cpp:126-139) into d_rgb[(n/spp)*3] -- the linear float framebuffer
+ * (tempImage, Scene.cpp:106).  All pointers are device pointers. */
+mr_status mr_shade_direct(mr_scene *scene, const mr_ray *d_rays, const mr_hit *d_hits, uint64_t n,
+                          const mr_hit *d_shadow_hits, const uint32_t *d_shadow_src, const uint64_t *d_shadow_count,
+                          const mr_light *light, const float diffuse[3], uint32_t spp, float *d_rgb, void *stream);
+/* sigmoid(6v-3) tone map + 8-bit quantisation (Scene.cpp:87-91,177-202; Image.cpp:44-50) */
+mr_status mr_tonemap(mr_scene *scene, const float *d_rgb, uint64_t n_values, uint8_t *d_out, void *stream);
 
 const char *mr_last_error(void);
 const char *mr_version(void);

@@ -96,6 +96,13 @@ uint64_t orc_shadow_rays(const orc_scene *, const orc_ray *rays, const orc_hit *
 /* HitInfo reconstruction: P (Triangle.cpp:160), N un-normalised (Triangle.cpp:162). */
 void orc_hit_attrs(const orc_scene *, const orc_hit *hits, uint64_t n, float *P, float *N);
 
+/* Phong::shade for one point light + per-pixel sample average; occluded[i] = shadow ray of primary ray i
+ * hit something.  rgb: (n/spp)*3 linear floats.  (miro_oracle_shade.c) */
+void orc_shade_direct(const orc_scene *, const orc_ray *rays, const orc_hit *hits, uint64_t n,
+                      const unsigned char *occluded, const float light[3], const float color[3],
+                      float wattage, const float diffuse[3], int spp, float *rgb);
+void orc_tonemap(const float *rgb, uint64_t n_values, unsigned char *out);
+
 uint32_t orc_hash(uint32_t x);
 
 #ifdef __cplusplus

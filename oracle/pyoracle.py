@@ -65,6 +65,8 @@ def lib():
         L.orc_shadow_rays.argtypes = [vp, vp, vp, C.c_uint64, f32p, vp, u64p, C.c_int]
         L.orc_shadow_rays.restype = C.c_uint64
         L.orc_hit_attrs.argtypes = [vp, vp, C.c_uint64, f32p, f32p]
+        L.orc_shade_direct.argtypes = [vp, vp, vp, C.c_uint64, vp, f32p, f32p, C.c_float, f32p, C.c_int, f32p]
+        L.orc_tonemap.argtypes = [f32p, C.c_uint64, vp]
         L.orc_hash.argtypes = [C.c_uint32]
         L.orc_hash.restype = C.c_uint32
         _lib = L
@@ -192,12 +194,29 @@ class Scene:
                                    out.ctypes.data, src.ctypes.data_as(C.POINTER(C.c_uint64)), 1 if sse_order else 0)
         return out[:k].copy(), src[:k].copy()
 
+    def shade_direct(self, rays, hits, occluded, light, wattage, spp=1, color=(1, 1, 1), diffuse=(1, 1, 1)):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        occ = np.ascontiguousarray(occluded, dtype=np.uint8)
+        rgb = np.empty((len(rays) // spp, 3), np.float32)
+        l, c, d = (np.ascontiguousarray(x, dtype=np.float32) for x in (light, color, diffuse))
+        self.L.orc_shade_direct(self.h, rays.ctypes.data, hits.ctypes.data, len(rays), occ.ctypes.data,
+                                _f32p(l), _f32p(c), wattage, _f32p(d), spp, _f32p(rgb))
+        return rgb
+
     def hit_attrs(self, hits):
         hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
         P = np.empty((len(hits), 3), np.float32)
         N = np.empty((len(hits), 3), np.float32)
         self.L.orc_hit_attrs(self.h, hits.ctypes.data, len(hits), _f32p(P), _f32p(N))
         return P, N
+
+
+def tonemap(rgb):
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    out = np.empty(rgb.shape, np.uint8)
+    lib().orc_tonemap(_f32p(rgb), rgb.size, out.ctypes.data)
+    return out
 
 
 def eye_rays(cam, W, H, spp=1, jitter=False, seed=168, y0=0, y1=None):

@@ -1,0 +1,160 @@
+"""The callers either side of the hot path: wavefront frame driver, Phong shading, image-tile sharding and
+the single framebuffer gather.  CPU part: sharding arithmetic + a world_size-2 gloo run of the gather.
+GPU part: shading parity with the oracle and shard-count independence of the frame."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import camera_of, oracle_scene, product_scene
+from miro_amd import frame as mframe
+from miro_amd import scenes
+
+
+# ------------------------------------------------------------------------------------------- CPU: sharding
+@pytest.mark.parametrize("H,band,world", [(1080, 8, 1), (1080, 8, 2), (1080, 8, 8), (1080, 16, 3), (37, 8, 4), (5, 8, 8)])
+def test_band_rows_partition_the_image(H, band, world):
+    seen = np.zeros(H, np.int32)
+    sizes = []
+    for r in range(world):
+        rows = mframe.rows_of(mframe.band_rows(H, band, r, world))
+        seen[rows] += 1
+        sizes.append(len(rows))
+        assert (np.diff(rows) > 0).all() if len(rows) > 1 else True
+    assert (seen == 1).all()                                   # every row exactly once
+    assert max(sizes) - min(sizes) <= band                     # balanced to within one band
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gather_worker(rank, world, port, H, W, band, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows = mframe.rows_of(mframe.band_rows(H, band, rank, world))
+    # each rank "renders" its rows: value encodes (row, column, channel)
+    local = torch.empty((len(rows), W, 3), dtype=torch.float32)
+    for i, y in enumerate(rows):
+        local[i] = (y * W + torch.arange(W, dtype=torch.float32))[:, None] * 4 + torch.arange(3, dtype=torch.float32)[None, :]
+    full = mframe.gather_framebuffer(local.reshape(-1, 3), H, W, band, rank, world)
+    if rank == 0:
+        torch.save(full, out_path)
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H,W,band", [(37, 5, 8), (64, 3, 8)])
+def test_gather_framebuffer_gloo_world2(tmp_path, H, W, band):
+    """The N>1 path on CPU: two processes, gloo, one gather; rank 0 reassembles the interleaved bands."""
+    out = str(tmp_path / "full.pt")
+    mp.spawn(_gather_worker, args=(2, _free_port(), H, W, band, out), nprocs=2, join=True)
+    full = torch.load(out, weights_only=True)
+    want = (torch.arange(H * W, dtype=torch.float32).reshape(H, W, 1) * 4 + torch.arange(3, dtype=torch.float32))
+    assert torch.equal(full, want)
+
+
+def test_gather_framebuffer_single_rank():
+    H, W = 20, 7
+    local = torch.arange(H * W * 3, dtype=torch.float32).reshape(-1, 3)
+    full = mframe.gather_framebuffer(local, H, W, 8, 0, 1)
+    assert torch.equal(full.reshape(-1, 3), local)
+
+
+# ------------------------------------------------------------------------------------------- GPU
+gpu = pytest.mark.gpu
+
+
+@gpu
+@pytest.mark.parametrize("name,spp", [("teapot", 1), ("bunny", 4), ("sponza", 2)])
+def test_frame_pipeline_matches_oracle(oracle, miro, name, spp):
+    """gen -> trace -> shadow gen -> indirect trace -> shade on the device vs the restated
+    raytraceImage / Phong::shade on the CPU: hits bit-exact, colours within 1e-5 (powf/rounding)."""
+    assert torch.cuda.is_available()
+    W, H = 160, 120
+    d = scenes.SCENES[name]
+    a = oracle_scene(oracle, name)
+    b = product_scene(miro, name)
+    fr = mframe.FrameRenderer(b, d, W, H, spp=spp)
+    fr.generate()
+    fr.step()
+    torch.cuda.synchronize()
+    rays = oracle.eye_rays(camera_of(oracle, name), W, H, spp=spp, jitter=spp > 1, seed=168)
+    hits = a.trace(rays)
+    assert fr.d_rays.cpu().numpy().tobytes() == rays.tobytes()
+    assert fr.d_hits.cpu().numpy().tobytes() == hits.tobytes()
+    sh, src = a.shadow_rays(rays, hits, d["light"])
+    sh_hits = a.trace(sh)
+    n_p, n_s = fr.ray_counts()
+    assert (n_p, n_s) == (len(rays), len(sh))
+    # shadow batch: same set of (source ray, hit) pairs
+    k = n_s
+    got_src = fr.d_src[:k].cpu().numpy().astype(np.int64)
+    order = np.argsort(got_src, kind="stable")
+    assert np.array_equal(got_src[order], src.astype(np.int64))
+    got_sh = fr.d_shadow_hits[:k].cpu().numpy().view(miro.HIT_DTYPE).reshape(-1)[order]
+    assert got_sh.tobytes() == sh_hits.tobytes()
+    occ = np.zeros(len(rays), np.uint8)
+    occ[src.astype(np.int64)] = sh_hits["prim"] != oracle.MISS
+    want = a.shade_direct(rays, hits, occ, d["light"], d["wattage"], spp=spp)
+    got = fr.d_rgb.cpu().numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+    assert want.max() > 0
+    # tone map + 8-bit quantisation: at most one code value apart (expf vs exp rounding at a boundary)
+    out = torch.empty(got.shape, dtype=torch.uint8, device="cuda")
+    b.tonemap(fr.d_rgb, got.size, out)
+    tm = oracle.tonemap(want)
+    assert np.abs(out.cpu().numpy().astype(np.int32) - tm.astype(np.int32)).max() <= 1
+
+
+@gpu
+def test_any_hit_shadow_batch_gives_the_same_image(oracle, miro):
+    """Opaque scene: occlusion from the any-hit query == occlusion from the closest-hit query."""
+    b = product_scene(miro, "bunny")
+    fr = mframe.FrameRenderer(b, "bunny", 200, 150, spp=2)
+    fr.generate()
+    fr.step(any_hit=False)
+    ref = fr.d_rgb.clone()
+    fr.step(any_hit=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ref, fr.d_rgb)
+
+
+@gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_tile_sharding_is_invisible_in_the_result(miro, world):
+    """SURVEY.md section 4 tier 4: the same frame sharded 1/2/4/8 ways gives byte-identical hit buffers and
+    framebuffer (here the shards run one after the other on the one GPU of the test box)."""
+    W, H, spp, band = 192, 100, 2, 8
+    b = product_scene(miro, "sponza")
+    whole = mframe.FrameRenderer(b, "sponza", W, H, spp=spp)
+    whole.generate()
+    whole.step()
+    torch.cuda.synchronize()
+    ref_rgb = whole.d_rgb.reshape(H, W, 3)
+    ref_hits = whole.d_hits.reshape(H, W * spp, 4)
+    full = torch.zeros_like(ref_rgb)
+    for r in range(world):
+        bands = mframe.band_rows(H, band, r, world)
+        fr = mframe.FrameRenderer(b, "sponza", W, H, spp=spp, bands=bands)
+        fr.generate()
+        fr.step()
+        torch.cuda.synchronize()
+        rows = torch.from_numpy(mframe.rows_of(bands)).cuda()
+        assert torch.equal(fr.d_hits.reshape(len(rows), W * spp, 4).view(torch.int32), ref_hits[rows].view(torch.int32))
+        part = mframe.gather_framebuffer(fr.d_rgb, H, W, band, 0, 1) if world == 1 else fr.d_rgb.reshape(len(rows), W, 3)
+        full[rows] = part
+    assert torch.equal(full.view(torch.int32), ref_rgb.view(torch.int32))

@@ -1,0 +1,347 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on identical
+seeded ray sets.  Bar: the default ("exact") mode is bit-exact in t / prim / beta / gamma and reproduces the
+reference's -DSTATS counters; MR_MATH_FAST is within the 1e-5 relative tolerance of BASELINE.json.
+/root/reference is not needed at run time: scenes come from tests/golden/models and the seeded atrium."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import (assert_hits_bit_exact, assert_hits_close, camera_of, oracle_scene, product_scene, random_rays)
+from miro_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+_cache = {}
+
+
+def both(oracle, miro, name, leaf=4):
+    key = (name, leaf)
+    if key not in _cache:
+        _cache[key] = (oracle_scene(oracle, name, leaf), product_scene(miro, name, leaf))
+    return _cache[key]
+
+
+def scene_box(s):
+    v = s.arrays()[0]
+    return v.min(0), v.max(0)
+
+
+# ----------------------------------------------------------------------------------------------- exact mode
+@pytest.mark.parametrize("name,W,H", [("cornell", 256, 256), ("teapot", 512, 512), ("bunny", 256, 256),
+                                      ("sponza", 256, 256), ("sphere", 64, 64), ("testobj", 64, 64)])
+def test_primary_rays_bit_exact(oracle, miro, torch_cuda, name, W, H):
+    """BASELINE configs 1-4 (reduced resolution where the oracle would take long): pixel-centre
+    eye rays, closest hit."""
+    a, b = both(oracle, miro, name)
+    rays = oracle.eye_rays(camera_of(oracle, name), W, H)
+    want = a.trace(rays)
+    got = b.trace(rays.view(miro.RAY_DTYPE))
+    assert_hits_bit_exact(got, want.view(miro.HIT_DTYPE))
+    assert (want["prim"] != oracle.MISS).any()
+
+
+@pytest.mark.parametrize("name", ["teapot", "bunny", "sponza"])
+def test_shadow_rays_bit_exact(oracle, miro, torch_cuda, name):
+    """Phong shadow batch (finite tMax, origins on surfaces): closest hit as the reference traces them."""
+    a, b = both(oracle, miro, name)
+    rays = oracle.eye_rays(camera_of(oracle, name), 192, 192)
+    hits = a.trace(rays)
+    sh, _ = a.shadow_rays(rays, hits, scenes.SCENES[name]["light"])
+    assert len(sh) > 1000
+    assert_hits_bit_exact(b.trace(sh.view(miro.RAY_DTYPE)), a.trace(sh).view(miro.HIT_DTYPE))
+
+
+@pytest.mark.parametrize("name", ["cornell", "teapot", "bunny", "sponza"])
+def test_incoherent_rays_bit_exact(oracle, miro, torch_cuda, name):
+    """Random origins and directions (divergent traversal, deep stacks, rays starting inside boxes)."""
+    a, b = both(oracle, miro, name)
+    lo, hi = scene_box(a)
+    lo, hi = np.maximum(lo, -20), np.minimum(hi, 20)
+    rays = random_rays(oracle.RAY_DTYPE, 20000, lo, hi, seed=11)
+    assert_hits_bit_exact(b.trace(rays.view(miro.RAY_DTYPE)), a.trace(rays).view(miro.HIT_DTYPE))
+
+
+def test_t_interval_and_degenerate_rays(oracle, miro, torch_cuda):
+    """tMin is inclusive at the triangle (Triangle.cpp:158); a hit at exactly t == tMax passes the triangle
+    test but loses the strict-less comparison against minHit.t = tMax (BVH.cpp:477,500), so it is a miss;
+    axis-parallel directions give
+    +-inf / NaN slab distances (BVH.cpp:451-457); zero-length direction; rays behind the origin."""
+    a, b = both(oracle, miro, "teapot")
+    base = oracle.eye_rays(camera_of(oracle, "teapot"), 96, 96)
+    ref = a.trace(base)
+    hit = ref["prim"] != oracle.MISS
+    cases = []
+    r = base[hit].copy(); r["tmax"] = ref["t"][hit]; cases.append(r)                       # t == tMax: miss
+    r = base[hit].copy(); r["tmax"] = np.nextafter(ref["t"][hit], np.float32(np.inf)); cases.append(r)   # one ulp more: hit
+    r = base[hit].copy(); r["tmin"] = ref["t"][hit]; cases.append(r)                       # t == tMin accepted
+    r = base[hit].copy(); r["tmin"] = np.nextafter(ref["t"][hit], np.float32(np.inf)); cases.append(r)
+    r = base.copy(); r["tmax"] = 0.0; cases.append(r)                                      # empty interval
+    r = base.copy(); r["dx"] *= -1; r["dy"] *= -1; r["dz"] *= -1; cases.append(r)          # pointing away
+    ax = np.zeros(6 * 400, oracle.RAY_DTYPE)                                               # axis-parallel
+    rng = np.random.RandomState(5)
+    for k, d in enumerate(((1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1))):
+        sl = slice(400 * k, 400 * (k + 1))
+        o = (rng.rand(400, 3).astype(np.float32) - 0.5) * 8
+        o[:, 1] = np.abs(o[:, 1])
+        o[:50] = np.round(o[:50] * 2) / 2            # some origins on "nice" coordinates
+        ax["ox"][sl], ax["oy"][sl], ax["oz"][sl] = (o[:, 0] - 6 * d[0]), (o[:, 1] - 6 * d[1]), (o[:, 2] - 6 * d[2])
+        ax["dx"][sl], ax["dy"][sl], ax["dz"][sl] = d
+        ax["tmax"][sl] = 1e12
+    cases.append(ax)
+    z = base[:64].copy(); z["dx"] = 0; z["dy"] = 0; z["dz"] = 0; cases.append(z)           # zero direction
+    neg0 = ax.copy(); neg0["dx"] = np.where(neg0["dx"] == 0, np.float32(-0.0), neg0["dx"]); cases.append(neg0)
+    for rays in cases:
+        assert_hits_bit_exact(b.trace(rays.view(miro.RAY_DTYPE)), a.trace(rays).view(miro.HIT_DTYPE))
+    # the bound cases really exercise both sides
+    assert (a.trace(cases[0])["prim"] == oracle.MISS).all()
+    assert (a.trace(cases[1])["prim"] != oracle.MISS).all()
+    assert (a.trace(cases[2])["prim"] != oracle.MISS).mean() > 0.99
+    assert (a.trace(cases[4])["prim"] == oracle.MISS).all()
+
+
+def test_edge_and_vertex_hits(oracle, miro, torch_cuda):
+    """Rays aimed exactly at shared edges and vertices of the mesh: the epsilon-slack barycentric test
+    accepts both neighbours and the strict-less / first-found rule decides (BVH.cpp:500)."""
+    a, b = both(oracle, miro, "sphere")
+    v, _, vi, _ = a.arrays()
+    eye = np.array([0.3, 0.2, 4.0], np.float32)
+    targets = [v[vi[:, 0]], v[vi[:, 1]], 0.5 * (v[vi[:, 0]] + v[vi[:, 1]]), 0.5 * (v[vi[:, 1]] + v[vi[:, 2]]),
+               (v[vi[:, 0]] + v[vi[:, 1]] + v[vi[:, 2]]) / 3]
+    tg = np.concatenate(targets).astype(np.float32)
+    d = tg - eye
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros(len(tg), oracle.RAY_DTYPE)
+    rays["ox"], rays["oy"], rays["oz"] = eye
+    rays["dx"], rays["dy"], rays["dz"] = d[:, 0], d[:, 1], d[:, 2]
+    rays["tmax"] = 1e12
+    want = a.trace(rays)
+    assert (want["prim"] != oracle.MISS).mean() > 0.9
+    assert_hits_bit_exact(b.trace(rays.view(miro.RAY_DTYPE)), want.view(miro.HIT_DTYPE))
+
+
+def test_empty_ragged_and_single_batches(oracle, miro, torch_cuda):
+    a, b = both(oracle, miro, "teapot")
+    rays = oracle.eye_rays(camera_of(oracle, "teapot"), 70, 61)      # 4270 rays: not a multiple of 64 or 256
+    want = a.trace(rays)
+    assert len(b.trace(rays[:0].view(miro.RAY_DTYPE))) == 0
+    for n in (1, 63, 64, 65, 255, 257, 4270):
+        assert_hits_bit_exact(b.trace(rays[:n].view(miro.RAY_DTYPE)), want[:n].view(miro.HIT_DTYPE))
+
+
+def test_degenerate_scenes(oracle, miro, torch_cuda):
+    """Root is a leaf; empty scene; a depth-32 leaf holding 40 triangles (count escape of the leaf reference)."""
+    rays = random_rays(oracle.RAY_DTYPE, 2000, (-1, -1, -1), (2, 2, 2), seed=3)
+    one_v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    one_n = np.array([[0, 0, 1]] * 3, np.float32)
+    f1 = np.array([[0, 1, 2]], np.uint32)
+    many_v = np.tile(np.array([[0.25, 0.5, -1.0], [1.5, 0.125, 0.75], [-0.5, 2.0, 0.5]], np.float32), (40, 1))
+    many_f = np.arange(120, dtype=np.uint32).reshape(40, 3)
+    for v, n, f in ((None, None, None), (one_v, one_n, f1), (many_v, np.tile(one_n[:1], (120, 1)), many_f)):
+        a, b = oracle.Scene(), miro.Scene()
+        if v is not None:
+            a.add_arrays(v, n, f, f)
+            b.add_arrays(v, n, f, f)
+        a.build(4)
+        b.build(4)
+        want = a.trace(rays)
+        assert_hits_bit_exact(b.trace(rays.view(miro.RAY_DTYPE)), want.view(miro.HIT_DTYPE))
+        got, stats_want = b.trace(rays.view(miro.RAY_DTYPE), miro.MR_COUNT_STATS), a.trace(rays, counters=True)[1]
+        assert b.stats() == stats_want
+
+
+# ----------------------------------------------------------------------------------------------- counters
+@pytest.mark.parametrize("name", ["teapot", "bunny"])
+def test_stats_counters_match_reference(oracle, miro, torch_cuda, golden_dir, name):
+    """-DSTATS on the device: the same node-visit and triangle-test counts as the reference's scalar
+    build (BASELINE.md section 2 = 512x512 render + stride-8 probe grid, see kat_counters.json)."""
+    k = json.load(open(os.path.join(golden_dir, "kat_counters.json")))["baseline"][name]
+    a, b = both(oracle, miro, name)
+    rays = oracle.eye_rays(camera_of(oracle, name), 512, 512)
+    b.stats()
+    hits = b.trace(rays.view(miro.RAY_DTYPE), miro.MR_COUNT_STATS)
+    primary = b.stats()
+    assert int((hits["prim"] != miro.MISS).sum()) == k["primary_hits"]
+    probe = rays.reshape(512, 512)[0::8, 0::8].reshape(-1).copy()
+    b.trace(probe.view(miro.RAY_DTYPE), miro.MR_COUNT_STATS)
+    pr = b.stats()
+    assert (primary[0] + pr[0], primary[1] + pr[1]) == (k["no_shadows"]["box_tests"], k["no_shadows"]["tri_tests"])
+    sh, _ = a.shadow_rays(rays, hits.view(oracle.HIT_DTYPE), scenes.SCENES[name]["light"])
+    b.trace(sh.view(miro.RAY_DTYPE), miro.MR_COUNT_STATS)
+    shc = b.stats()
+    assert (primary[0] + pr[0] + shc[0], primary[1] + pr[1] + shc[1]) == (k["shadows"]["box_tests"], k["shadows"]["tri_tests"])
+
+
+# ----------------------------------------------------------------------------------------------- fast mode
+@pytest.mark.parametrize("name", ["cornell", "teapot", "bunny", "sponza"])
+def test_fast_math_within_tolerance(oracle, miro, torch_cuda, name):
+    a, b = both(oracle, miro, name)
+    mesh = a.arrays()
+    rays = oracle.eye_rays(camera_of(oracle, name), 256, 256)
+    want = a.trace(rays)
+    got = b.trace(rays.view(miro.RAY_DTYPE), miro.MR_MATH_FAST)
+    def explain(got, want, flips):
+        # every flipped ray must be explainable: the alternative is at (almost) the same distance (two
+        # triangles sharing an edge both accept inside the epsilon slack), or the hit sat inside the
+        # slack band of an edge / at the end of the interval and one side rejected it
+        for i in flips:
+            g, w = got[i], want[i]
+            if g["prim"] != miro.MISS and w["prim"] != oracle.MISS:
+                assert abs(g["t"] - w["t"]) <= 1e-4 * max(1.0, abs(w["t"]))
+            else:
+                h = w if w["prim"] != oracle.MISS else g
+                assert min(h["beta"], h["gamma"], 1 - h["beta"] - h["gamma"]) < 1e-3
+
+    explain(got, want, assert_hits_close(got, want.view(miro.HIT_DTYPE), mesh, rays))
+    lo, hi = scene_box(a)
+    rr = random_rays(oracle.RAY_DTYPE, 20000, np.maximum(lo, -20), np.minimum(hi, 20), seed=21)
+    got, want = b.trace(rr.view(miro.RAY_DTYPE), miro.MR_MATH_FAST), a.trace(rr)
+    explain(got, want, assert_hits_close(got, want.view(miro.HIT_DTYPE), mesh, rr))
+
+
+# ----------------------------------------------------------------------------------------------- any-hit
+def test_any_hit_agrees_on_occlusion(oracle, miro, torch_cuda):
+    """MR_TRACE_ANY returns *a* valid hit inside [tMin,tMax] iff the closest-hit query hits."""
+    a, b = both(oracle, miro, "bunny")
+    rays = oracle.eye_rays(camera_of(oracle, "bunny"), 160, 160)
+    hits = a.trace(rays)
+    sh, _ = a.shadow_rays(rays, hits, scenes.SCENES["bunny"]["light"])
+    want = a.trace(sh)
+    got = b.trace(sh.view(miro.RAY_DTYPE), miro.MR_TRACE_ANY)
+    assert np.array_equal(got["prim"] != miro.MISS, want["prim"] != oracle.MISS)
+    occ = got["prim"] != miro.MISS
+    assert occ.any() and (got["t"][occ] >= want["t"][occ]).all() and (got["t"][occ] <= sh["tmax"][occ]).all()
+    # the reported hit is a genuine intersection of that primitive
+    chk = np.nonzero(occ)[0][:200]
+    for i in chk:
+        one = sh[i:i + 1].copy()
+        one["tmin"] = got["t"][i]
+        one["tmax"] = np.nextafter(got["t"][i], np.float32(np.inf))     # t == tMax itself is a miss
+        again = a.trace_brute(one)
+        assert again["prim"][0] != oracle.MISS
+
+
+# ----------------------------------------------------------------------------------------------- device-side callers
+def test_device_buffers_and_streams(oracle, miro, torch_cuda):
+    """Device-resident rays/hits on a side stream; result identical to the staged host path."""
+    torch = torch_cuda
+    a, b = both(oracle, miro, "teapot")
+    rays = oracle.eye_rays(camera_of(oracle, "teapot"), 200, 150)
+    d_rays = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
+    d_hits = torch.empty((len(rays), 4), dtype=torch.float32, device="cuda")
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        b.trace_device(d_rays, len(rays), d_hits, stream=st)
+    st.synchronize()
+    got = d_hits.cpu().numpy().view(miro.HIT_DTYPE).reshape(-1)
+    assert_hits_bit_exact(got, a.trace(rays).view(miro.HIT_DTYPE))
+    with pytest.raises(miro.MiroError):        # misaligned device pointer is refused, not faulted on
+        b.trace_device(d_rays.data_ptr() + 4, 8, d_hits)
+
+
+@pytest.mark.parametrize("name,spp,jitter", [("teapot", 1, False), ("bunny", 4, True), ("sponza", 2, True)])
+def test_eye_ray_generator_bit_exact(oracle, miro, torch_cuda, name, spp, jitter):
+    """Camera::eyeRay on the device == the restated Camera.cpp:104-161 (bitwise), incl. row windows."""
+    torch = torch_cuda
+    _, b = both(oracle, miro, name)
+    W, H = 97, 64
+    want = oracle.eye_rays(camera_of(oracle, name), W, H, spp=spp, jitter=jitter, seed=168)
+    d = torch.empty((W * H * spp, 8), dtype=torch.float32, device="cuda")
+    from miro_amd import binding
+    cam = camera_of(binding, name)
+    n = b.gen_eye_rays(cam, W, H, d, spp=spp, jitter=jitter, seed=168)
+    assert n == len(want)
+    got = d.cpu().numpy().view(miro.RAY_DTYPE).reshape(-1)
+    assert got.tobytes() == want.tobytes()
+    n2 = b.gen_eye_rays(cam, W, H, d, y0=10, y1=20, spp=spp, jitter=jitter, seed=168)
+    got2 = d[:n2].cpu().numpy().view(miro.RAY_DTYPE).reshape(-1)
+    assert got2.tobytes() == want[10 * W * spp:20 * W * spp].tobytes()
+
+
+@pytest.mark.parametrize("name", ["teapot", "bunny", "sponza"])
+def test_shadow_ray_generator_and_hit_attrs(oracle, miro, torch_cuda, name):
+    """Phong shadow rays built on the device (ballot compaction): same set of rays, bitwise, as the
+    restated Phong.cpp:80-97; P and N as Triangle.cpp:160,162."""
+    torch = torch_cuda
+    a, b = both(oracle, miro, name)
+    rays = oracle.eye_rays(camera_of(oracle, name), 150, 130)
+    hits = a.trace(rays)
+    light = scenes.SCENES[name]["light"]
+    want, src_want = a.shadow_rays(rays, hits, light)
+    n = len(rays)
+    d_hits = torch.from_numpy(hits.view(np.float32).reshape(-1, 4).copy()).cuda()
+    d_out = torch.empty((n, 8), dtype=torch.float32, device="cuda")
+    d_src = torch.empty(n, dtype=torch.int32, device="cuda")
+    d_cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    b.gen_shadow_rays(None, d_hits, n, light, d_out, d_src, d_cnt)
+    k = int(d_cnt.item())
+    assert k == len(want)
+    src = d_src[:k].cpu().numpy().astype(np.int64)
+    order = np.argsort(src, kind="stable")
+    assert np.array_equal(src[order], src_want.astype(np.int64))
+    got = d_out[:k].cpu().numpy().view(miro.RAY_DTYPE).reshape(-1)[order]
+    assert got.tobytes() == want.tobytes()
+    # compaction is wave-granular: within a wave the source order is preserved
+    assert (np.diff(src.reshape(-1)) != 0).all()
+    P = torch.empty((n, 3), dtype=torch.float32, device="cuda")
+    N = torch.empty((n, 3), dtype=torch.float32, device="cuda")
+    b.hit_attrs(d_hits, n, P, N)
+    Pw, Nw = a.hit_attrs(hits)
+    assert np.array_equal(P.cpu().numpy().view(np.uint32), Pw.view(np.uint32))
+    assert np.array_equal(N.cpu().numpy().view(np.uint32), Nw.view(np.uint32))
+
+
+# ----------------------------------------------------------------------------------------------- full-size properties
+def test_full_size_properties(oracle, miro, torch_cuda):
+    """BASELINE-size batch (1920x1080, 4 spp of config 4) through size-independent properties:
+    (1) any prefix / permutation of the batch gives the same per-ray hits (rays are independent);
+    (2) re-tracing with tMax = t hits the same primitive at the same t (idempotence);
+    (3) shortening tMax below t turns every hit into a miss or a nearer-than-before impossibility;
+    (4) a sub-sample agrees bit-for-bit with the oracle."""
+    torch = torch_cuda
+    a, b = both(oracle, miro, "sponza")
+    from miro_amd import binding
+    W, H, spp = 1920, 1080, 4
+    n = W * H * spp
+    d_rays = torch.empty((n, 8), dtype=torch.float32, device="cuda")
+    d_hits = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    b.gen_eye_rays(camera_of(binding, "sponza"), W, H, d_rays, spp=spp, jitter=True, seed=168)
+    b.trace_device(d_rays, n, d_hits)
+    torch.cuda.synchronize()
+    hits_bits = d_hits.view(torch.int32)
+    # closed scene: every primary ray hits
+    assert int((hits_bits[:, 1] == -1).sum()) == 0
+    # (1) permutation
+    perm = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    d_hits2 = torch.empty_like(d_hits)
+    b.trace_device(d_rays[perm].contiguous(), n, d_hits2)
+    torch.cuda.synchronize()
+    assert torch.equal(d_hits2.view(torch.int32), hits_bits[perm])
+    # (2) idempotence with tMax one ulp above t (t == tMax itself loses the strict-less test, BVH.cpp:500)
+    r2 = d_rays.clone()
+    r2[:, 7] = torch.nextafter(d_hits[:, 0], torch.full_like(d_hits[:, 0], float("inf")))
+    b.trace_device(r2, n, d_hits2)
+    torch.cuda.synchronize()
+    assert torch.equal(d_hits2.view(torch.int32), hits_bits)
+    # (3) tMax = t: no hit can be the old one
+    r2[:, 7] = d_hits[:, 0]
+    b.trace_device(r2, n, d_hits2)
+    torch.cuda.synchronize()
+    still = d_hits2.view(torch.int32)[:, 1] != -1
+    assert bool((d_hits2[:, 0][still] < d_hits[:, 0][still]).all())
+    # (4) sub-sample against the oracle
+    idx = torch.arange(0, n, 4099, device="cuda")
+    sub = d_rays[idx].cpu().numpy().view(oracle.RAY_DTYPE).reshape(-1)
+    want = a.trace(sub)
+    got = d_hits[idx].cpu().numpy().view(miro.HIT_DTYPE).reshape(-1)
+    assert_hits_bit_exact(got, want.view(miro.HIT_DTYPE))

@@ -1,0 +1,67 @@
+"""Quick device-side timing of mr_trace on the BASELINE scenes (development aid, not the bench contract).
+usage: python tools/perf_probe.py [scene ...] [--w 1920 --h 1080 --spp 4 --reps 5]"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "cse168-raytracer_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import miro_amd  # noqa: E402
+from miro_amd import binding, scenes  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("scenes", nargs="*", default=["teapot", "bunny", "sponza"])
+    ap.add_argument("--w", type=int, default=1920)
+    ap.add_argument("--h", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=4)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--leaf", type=int, default=4)
+    a = ap.parse_args()
+    stream = torch.cuda.current_stream()
+    for name in a.scenes:
+        d = scenes.SCENES[name]
+        sc = miro_amd.Scene(0)
+        t0 = time.time()
+        scenes.populate(sc, d)
+        info = sc.build(a.leaf)
+        tb = time.time() - t0
+        n = a.w * a.h * a.spp
+        d_rays = torch.empty((n, 8), dtype=torch.float32, device="cuda")
+        d_hits = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+        d_sh = torch.empty((n, 8), dtype=torch.float32, device="cuda")
+        d_shh = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+        d_cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        cam = binding.make_camera(d["eye"], d["lookat"], d["up"], d["fov"])
+        sc.gen_eye_rays(cam, a.w, a.h, d_rays, spp=a.spp, jitter=a.spp > 1, stream=stream)
+        sc.trace_device(d_rays, n, d_hits, stream=stream)
+        sc.gen_shadow_rays(d_rays, d_hits, n, d["light"], d_sh, None, d_cnt, stream=stream)
+        torch.cuda.synchronize()
+        ns = int(d_cnt.item())
+        print("%s: %d tris, %d nodes (depth %d), build+load %.2fs, %d primary, %d shadow rays" %
+              (name, info.n_triangles, info.n_nodes, info.max_depth, tb, n, ns))
+        for label, flags in (("exact", 0), ("fast", miro_amd.MR_MATH_FAST)):
+            for what, rays, cnt, hits, extra in (("primary", d_rays, n, d_hits, 0), ("shadow", d_sh, ns, d_shh, 0),
+                                                 ("shadow-any", d_sh, ns, d_shh, miro_amd.MR_TRACE_ANY)):
+                if cnt == 0:
+                    continue
+                sc.trace_device(rays, cnt, hits, flags | extra, stream=stream)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(a.reps):
+                    sc.trace_device(rays, cnt, hits, flags | extra, stream=stream)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / a.reps
+                print("  %-5s %-10s %8.3f ms  %9.1f Mrays/s" % (label, what, ms, cnt / ms / 1e3))
+        sc.close()
+
+
+if __name__ == "__main__":
+    main()
