@@ -290,29 +290,55 @@ __device__ __forceinline__ void hit_point(const MeshPtrs &m, uint32_t prim, floa
     Pz = (az + beta * bz) + gamma * cz;
 }
 
+// Compaction is hierarchical so that the global counter sees one atomic per 2048 rays, not one per wave
+// (a single counter word saturates at ~88 atomics/us, MI355X_MICROARCH.md "dequeue"): each workgroup takes
+// chunks of kBlock*kShIter rays; every wave ballots its kShIter sub-rows (wave64 __ballot + popcount
+// prefix), wave totals meet in LDS, lane 0 reserves the chunk's range with one atomicAdd, and each lane
+// writes at  chunk base + waves before mine + sub-rows before this one + lanes before mine.
+constexpr int kShIter = 8;
+
 __global__ __launch_bounds__(kBlock) void shadow_rays_kernel(MeshPtrs m, const mr_hit *hits, unsigned long long n,
                                                              float Lx, float Ly, float Lz, mr_ray *out,
                                                              uint32_t *src, unsigned long long *count) {
-    const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
-    const unsigned long long n_round = (n + 63ull) & ~63ull;       // keep whole waves in the loop
-    for (unsigned long long k = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; k < n_round; k += stride) {
-        float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
-        bool is_hit = false;
-        if (k < n) {
-            h = reinterpret_cast<const float4 *>(hits)[k];
-            is_hit = __float_as_uint(h.y) != MR_MISS;
+    __shared__ unsigned s_wave_total[kBlock / 64];
+    __shared__ unsigned long long s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long chunk = (unsigned long long)kBlock * kShIter;
+    const unsigned long long n_chunks = (n + chunk - 1) / chunk;
+    for (unsigned long long c = blockIdx.x; c < n_chunks; c += gridDim.x) {      // uniform per workgroup
+        float4 h[kShIter];
+        unsigned prefix[kShIter];     // hits of this wave in earlier sub-rows + earlier lanes of this one
+        unsigned wave_hits = 0;
+#pragma unroll
+        for (int it = 0; it < kShIter; it++) {
+            const unsigned long long k = c * chunk + (unsigned long long)it * kBlock + threadIdx.x;
+            bool is_hit = false;
+            h[it] = make_float4(0.f, __uint_as_float(MR_MISS), 0.f, 0.f);
+            if (k < n) {
+                h[it] = reinterpret_cast<const float4 *>(hits)[k];
+                is_hit = __float_as_uint(h[it].y) != MR_MISS;
+            }
+            const unsigned long long mask = __ballot(is_hit);
+            prefix[it] = wave_hits + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+            wave_hits += (unsigned)__popcll(mask);
         }
-        const unsigned long long mask = __ballot(is_hit);
-        if (mask == 0ull) continue;
-        unsigned long long base = 0;
-        const int lane = threadIdx.x & 63;
-        const int leader = __ffsll((long long)mask) - 1;
-        if (lane == leader) base = atomicAdd(count, (unsigned long long)__popcll(mask));
-        base = __shfl(base, leader, 64);
-        if (is_hit) {
-            const unsigned long long slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave_total[wave] = wave_hits;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned tot = 0;
+            for (int w = 0; w < kBlock / 64; w++) tot += s_wave_total[w];
+            s_base = tot ? atomicAdd(count, (unsigned long long)tot) : 0ull;
+        }
+        __syncthreads();
+        unsigned long long wave_base = s_base;
+        for (int w = 0; w < wave; w++) wave_base += s_wave_total[w];
+#pragma unroll
+        for (int it = 0; it < kShIter; it++) {
+            if (__float_as_uint(h[it].y) == MR_MISS) continue;
+            const unsigned long long k = c * chunk + (unsigned long long)it * kBlock + threadIdx.x;
+            const unsigned long long slot = wave_base + prefix[it];
             float Px, Py, Pz;
-            hit_point(m, __float_as_uint(h.y), h.z, h.w, Px, Py, Pz);
+            hit_point(m, __float_as_uint(h[it].y), h[it].z, h[it].w, Px, Py, Pz);
             float lx = Lx - Px, ly = Ly - Py, lz = Lz - Pz;           // PointLight::getLightDirection
             const float falloff = (lx * lx + ly * ly) + lz * lz;
             const float len = sqrtf(falloff);
@@ -324,6 +350,7 @@ __global__ __launch_bounds__(kBlock) void shadow_rays_kernel(MeshPtrs m, const m
             reinterpret_cast<float4 *>(out)[2 * slot + 1] = b;
             if (src) src[slot] = (uint32_t)k;
         }
+        __syncthreads();              // s_wave_total / s_base are reused by the next chunk
     }
 }
 

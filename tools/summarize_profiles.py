@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 passes of tools/collect_profiles.sh into the files that get committed under
+profiles/: the kernel-stats table, the per-launch HBM traffic of the trace kernel (PMC FETCH_SIZE /
+WRITE_SIZE, corrected as MI355X_MICROARCH.md section HBM prescribes) and a short markdown summary.
+
+usage: summarize_profiles.py <gpurun_out/prof_TAG> <TAG>
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def find(d, pat):
+    f = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
+    return f[0] if f else None
+
+
+def short(name):
+    m = re.search(r"(trace_kernel<[^>]*>|[a-z_]+_kernel)", name)
+    return m.group(1) if m else name[:60]
+
+
+def counter_table(path, counter):
+    """kernel short name -> list of per-dispatch counter values"""
+    out = {}
+    if not path:
+        return out
+    with open(path) as fh:
+        for row in csv.DictReader(fh):
+            if row.get("Counter_Name") != counter:
+                continue
+            out.setdefault(short(row["Kernel_Name"]), []).append(float(row["Counter_Value"]))
+    return out
+
+
+def main():
+    d, tag = sys.argv[1], sys.argv[2]
+    # on the GPU box only gpurun_out/ travels back: write next to the raw passes, copy into profiles/ afterwards
+    pdir = sys.argv[3] if len(sys.argv) > 3 else os.path.join(d, "for_profiles")
+    os.makedirs(pdir, exist_ok=True)
+    stats = find(os.path.join(d, "trace"), "*kernel_stats.csv")
+    bench_line = None
+    for line in open(os.path.join(d, "trace.log"), errors="replace"):
+        if line.startswith("{") and '"metric"' in line:
+            bench_line = json.loads(line)
+    rows = []
+    if stats:
+        with open(stats) as fh:
+            rows = list(csv.DictReader(fh))
+        with open(os.path.join(pdir, "%s_kernel_stats.csv" % tag), "w") as out:
+            w = csv.writer(out)
+            w.writerow(["kernel", "calls", "total_ms", "avg_ms", "percent", "min_ms", "max_ms"])
+            for r in rows:
+                w.writerow([short(r["Name"]), r["Calls"], "%.3f" % (float(r["TotalDurationNs"]) / 1e6),
+                            "%.4f" % (float(r["AverageNs"]) / 1e6), r["Percentage"],
+                            "%.4f" % (float(r["MinNs"]) / 1e6), "%.4f" % (float(r["MaxNs"]) / 1e6)])
+    fetch = counter_table(find(os.path.join(d, "pmc_fetch"), "*counter_collection.csv"), "FETCH_SIZE")
+    write = counter_table(find(os.path.join(d, "pmc_write"), "*counter_collection.csv"), "WRITE_SIZE")
+
+    md = ["# rocprofv3 summary `%s`" % tag, ""]
+    if bench_line:
+        md += ["bench line of the profiled run (profiled passes run at a lower clock; do not compare with un-profiled numbers):",
+               "", "```json", json.dumps(bench_line), "```", ""]
+    md += ["## kernel-trace --stats", "", "| kernel | calls | avg ms | total ms | % |", "|---|---|---|---|---|"]
+    for r in rows[:12]:
+        md.append("| `%s` | %s | %.4f | %.3f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e6,
+                                                         float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
+    md += ["", "## PMC passes (FETCH_SIZE / WRITE_SIZE, KiB per dispatch, averaged over dispatches)", "",
+           "| kernel | dispatches | FETCH_SIZE KiB | WRITE_SIZE KiB |", "|---|---|---|---|"]
+    kernels = sorted(set(fetch) | set(write))
+    for k in kernels:
+        f, w = fetch.get(k, []), write.get(k, [])
+        md.append("| `%s` | %d | %s | %s |" % (k, max(len(f), len(w)),
+                                               "%.1f" % (sum(f) / len(f)) if f else "-", "%.1f" % (sum(w) / len(w)) if w else "-"))
+
+    traffic = None
+    main_k = [k for k in kernels if k.startswith("trace_kernel<true, false, false>")]
+    if bench_line and main_k and fetch.get(main_k[0]) and write.get(main_k[0]):
+        k = main_k[0]
+        cfg = bench_line["config"]
+        # the timed launches are the big ones; the STATS pre-pass uses another template instance
+        f = [x for x in fetch[k] if x > 0.5 * max(fetch[k])]
+        w = [x for x in write[k] if x > 0.5 * max(write[k])]
+        rays_per_launch = cfg["rays_per_step"] / 2.0
+        # calibration (MI355X_MICROARCH.md: FETCH_SIZE reads 1/2 of a wide coalesced stream on gfx950; WRITE_SIZE is
+        # exact for 16 B/lane stores): the shadow-ray generator streams 16 B per hit in and 36 B per shadow ray out
+        cal = None
+        sk = [x for x in kernels if x.startswith("shadow_rays_kernel")]
+        if sk and fetch.get(sk[0]):
+            fs = max(fetch[sk[0]])
+            cal = (rays_per_launch * 16.0) / (fs * 1024.0)
+        fetch_bytes = sum(f) / len(f) * 1024.0 * 2.0
+        write_bytes = sum(w) / len(w) * 1024.0
+        traffic = {
+            "workload": cfg["workload"], "tag": tag, "kernel": k,
+            "fetch_size_kib_raw": sum(f) / len(f), "write_size_kib_raw": sum(w) / len(w),
+            "fetch_correction": 2.0, "fetch_calibration_from_shadow_rays_kernel": cal,
+            "hbm_bytes_per_launch": fetch_bytes + write_bytes,
+            "hbm_bytes_per_ray": (fetch_bytes + write_bytes) / rays_per_launch,
+            "algorithmic_stream_bytes_per_ray": 48.0,
+        }
+        with open(os.path.join(pdir, "%s_traffic.json" % tag), "w") as out:
+            json.dump(traffic, out, indent=1)
+        md += ["", "## HBM traffic of the trace kernel", "",
+               "FETCH_SIZE x 2 (gfx950 reports half of a wide coalesced read stream; the shadow-ray generator, which "
+               "streams a known 16 B per hit, gives a measured factor of %s) + WRITE_SIZE, per launch of ~%.0f M rays:" %
+               ("%.2f" % cal if cal else "n/a", rays_per_launch / 1e6), "",
+               "* %.1f MB per launch = **%.1f B per ray** (rays in + hits out are 48 B per ray; the node / triangle "
+               "records are served by L2 / Infinity Cache)" % (traffic["hbm_bytes_per_launch"] / 1e6, traffic["hbm_bytes_per_ray"])]
+    with open(os.path.join(pdir, "%s_summary.md" % tag), "w") as out:
+        out.write("\n".join(md) + "\n")
+    print("\n".join(md))
+    if traffic:
+        print(json.dumps(traffic))
+
+
+if __name__ == "__main__":
+    main()
