@@ -60,6 +60,13 @@ def main():
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / a.reps
                 print("  %-5s %-10s %8.3f ms  %9.1f Mrays/s" % (label, what, ms, cnt / ms / 1e3))
+        # PCIe-inclusive rate of the host-buffer form of mr_trace (pageable numpy arrays, staged by the library)
+        h_rays = d_rays.cpu().numpy().view(miro_amd.RAY_DTYPE).reshape(-1)
+        sc.trace(h_rays[:1024])
+        t0 = time.time()
+        sc.trace(h_rays)
+        dt = time.time() - t0
+        print("  host-buffer mr_trace (H2D 32 B/ray + D2H 16 B/ray included): %8.1f ms  %9.1f Mrays/s" % (dt * 1e3, n / dt / 1e6))
         sc.close()
 
 
