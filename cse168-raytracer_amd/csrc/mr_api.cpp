@@ -38,6 +38,7 @@ void release_device(mr_scene *s) {
     (void)hipFree(d.v); (void)hipFree(d.n); (void)hipFree(d.vi); (void)hipFree(d.ni);
     d = DeviceScene();
     (void)hipFree(s->d_stats); s->d_stats = nullptr;
+    (void)hipFree(s->d_work_counters); s->d_work_counters = nullptr;
     (void)hipFree(s->d_stage_rays); (void)hipFree(s->d_stage_hits);
     s->d_stage_rays = s->d_stage_hits = nullptr;
     s->stage_cap = 0;
@@ -121,6 +122,8 @@ mr_status flatten_and_upload(mr_scene *s) {
     d.stack_depth = t.max_depth + 1;
     MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&s->d_stats), 2 * sizeof(unsigned long long)));
     MR_HIP_CHECK(hipMemset(s->d_stats, 0, 2 * sizeof(unsigned long long)));
+    MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&s->d_work_counters), kWorkCounters * sizeof(unsigned long long)));
+    MR_HIP_CHECK(hipMemset(s->d_work_counters, 0, kWorkCounters * sizeof(unsigned long long)));
     return MR_OK;
 }
 
@@ -319,6 +322,7 @@ mr_status mr_trace(mr_scene *s, const mr_ray *rays, uint64_t n, mr_hit *hits, ui
     p.root_ref = s->dev.root_ref;
     p.stack_depth = (int32_t)s->dev.stack_depth;
     p.rays = d_rays; p.hits = d_hits; p.n = n; p.n_dev = nullptr; p.stats = s->d_stats;
+    p.work_counter = s->d_work_counters + (s->next_counter.fetch_add(1) % kWorkCounters);
     if ((st = launch_trace(p, flags, stream)) != MR_OK) return st;
     if (!hits_dev) {
         MR_HIP_CHECK(hipMemcpyAsync(hits, d_hits, n * sizeof(mr_hit), hipMemcpyDeviceToHost, stream));
@@ -348,6 +352,7 @@ mr_status mr_trace_indirect(mr_scene *s, const mr_ray *d_rays, const uint64_t *d
     p.rays = d_rays; p.hits = d_hits; p.n = max_rays;
     p.n_dev = reinterpret_cast<const unsigned long long *>(d_count);
     p.stats = s->d_stats;
+    p.work_counter = s->d_work_counters + (s->next_counter.fetch_add(1) % kWorkCounters);
     return launch_trace(p, flags, static_cast<hipStream_t>(stream_v));
 }
 

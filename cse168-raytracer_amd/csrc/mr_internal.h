@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -66,6 +67,7 @@ mr_status build_reference_tree(const HostMesh &mesh, uint32_t leaf_size, HostTre
 //   (A.x, A.y, A.z, BmA.x) (BmA.y, BmA.z, CmA.x, CmA.y) (CmA.z, n.x, n.y, n.z),  n = BmA x CmA
 constexpr int kLeafCountBits = 4;
 constexpr int kLeafCountMask = 15;
+constexpr uint32_t kWorkCounters = 64;   // launches in flight on different streams each get their own counter
 
 struct DeviceScene {
     float4   *nodes = nullptr;         // 4 * n_inner
@@ -94,6 +96,7 @@ struct TraceParams {
     unsigned long long n;                 // number of rays (upper bound when n_dev is set)
     const unsigned long long *n_dev;      // optional device-resident ray count (mr_trace_indirect)
     unsigned long long *stats;   // [0] box tests, [1] triangle tests (MR_COUNT_STATS)
+    unsigned long long *work_counter;     // zeroed per launch: ray hand-out counter of the persistent kernel
 };
 
 mr_status launch_trace(const TraceParams &p, uint32_t flags, hipStream_t stream);
@@ -121,6 +124,8 @@ struct mr_scene {
     bool on_device = false;   // device records uploaded
     mr::DeviceScene dev;
     unsigned long long *d_stats = nullptr;
+    unsigned long long *d_work_counters = nullptr;   // ring of kWorkCounters hand-out counters
+    std::atomic<uint32_t> next_counter{0};
     // grow-only staging buffers for host-pointer traces
     void *d_stage_rays = nullptr, *d_stage_hits = nullptr;
     uint64_t stage_cap = 0;

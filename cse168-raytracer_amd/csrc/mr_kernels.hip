@@ -16,12 +16,19 @@
 // fetched as 3 x dwordx4 (layout in mr_internal.h).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "mr_internal.h"
 
 namespace mr {
 namespace {
 
 constexpr int kBlock = 256;          // 4 waves per workgroup
+// Default 11 = min/max slabs on (corner - o) * (1/d) + while-while + wave-uniform nodes/leaves through the scalar
+// cache: bit-identical to variant 0 (the literal select form) on 3 scenes x (33 M primary + 33 M shadow + 16 M random rays), tools/ab_variants.py.  Variant 7 (lean fma
+// slabs) is NOT: a handful of shadow rays per 33 M change (boxes ending within ~1e-6 of a ray origin on a surface),
+// for a 2 % gain -- it is used by MR_MATH_FAST only.
+constexpr int kDefaultVariant = 11;  // see trace_kernel's VAR and trace_variant()
 constexpr float kEps = 1e-4f;        // Miro.h:9
 constexpr float kInf = __builtin_huge_valf();
 
@@ -55,7 +62,50 @@ struct RayRegs {
     float ix, iy, iz;                 // 1/d
     float mx_, my_, mz_;              // -d (Triangle.cpp:152 uses dot(-r.d, ...))
     float tmin;
+    float nox, noy, noz;              // -(o * 1/d): slab distance = fma(corner, 1/d, nox)   (lean slab form)
 };
+
+__device__ __forceinline__ void ray_setup(RayRegs &r, const float4 ra, const float4 rb) {
+    r.ox = ra.x; r.oy = ra.y; r.oz = ra.z; r.tmin = ra.w;
+    r.dx = rb.x; r.dy = rb.y; r.dz = rb.z;
+    r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+    r.mx_ = -r.dx; r.my_ = -r.dy; r.mz_ = -r.dz;
+    r.nox = -(r.ox * r.ix); r.noy = -(r.oy * r.iy); r.noz = -(r.oz * r.iz);
+}
+
+// A slab distance (corner - o) * (1/d) -- or fma(corner, 1/d, -(o/d)) -- can only be NaN as 0*inf, inf*0 or
+// inf-inf: with o, d, 1/d and o/d all finite (corners are finite or +-inf) none of these can occur, and the
+// select form of the reference and the min/max forms take the same decisions.
+__device__ __forceinline__ bool lane_is_nan_free(const RayRegs &r) {
+    return (__builtin_fabsf(r.ox) < kInf) && (__builtin_fabsf(r.oy) < kInf) && (__builtin_fabsf(r.oz) < kInf) &&
+           (__builtin_fabsf(r.dx) < kInf) && (__builtin_fabsf(r.dy) < kInf) && (__builtin_fabsf(r.dz) < kInf) &&
+           (__builtin_fabsf(r.ix) < kInf) && (__builtin_fabsf(r.iy) < kInf) && (__builtin_fabsf(r.iz) < kInf) &&
+           (__builtin_fabsf(r.nox) < kInf) && (__builtin_fabsf(r.noy) < kInf) && (__builtin_fabsf(r.noz) < kInf);
+}
+
+// three-input min/max in one VALU op; inline asm so that no canonicalising v_max x,x is inserted
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float o;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+    return o;
+}
+__device__ __forceinline__ float vmin3(float a, float b, float c) {
+    float o;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+    return o;
+}
+
+// Lean slab test of one child box for NaN-free rays: 6 fma + 3 min + 3 max + max3 + min3.  Entry/exit
+// distances differ from (corner - o) * (1/d) by rounding only; the decisions taken from them (cull, order) are
+// protected by the epsilon padding of every box (BVH.cpp:75-79) -- see DESIGN.md section 5.
+__device__ __forceinline__ void slab_box_lean(float lox, float hix, float loy, float hiy, float loz, float hiz,
+                                              const RayRegs &r, float &mn, float &mx) {
+    const float ax = fmaf(lox, r.ix, r.nox), bx = fmaf(hix, r.ix, r.nox);
+    const float ay = fmaf(loy, r.iy, r.noy), by = fmaf(hiy, r.iy, r.noy);
+    const float az = fmaf(loz, r.iz, r.noz), bz = fmaf(hiz, r.iz, r.noz);
+    mn = vmax3(fminf(ax, bx), fminf(ay, by), fminf(az, bz));
+    mx = vmin3(fmaxf(ax, bx), fmaxf(ay, by), fmaxf(az, bz));
+}
 
 // ---------------------------------------------------------------------------------------------------
 // Triangle::intersect (Triangle.cpp:150-158).  q0..q2 = the 48-byte record.  Returns true when the
@@ -93,125 +143,248 @@ __device__ __forceinline__ bool tri_test(const float4 q0, const float4 q1, const
 }
 
 // ---------------------------------------------------------------------------------------------------
-// closest-hit / any-hit traversal, one ray per lane
+// closest-hit / any-hit traversal, one ray per lane.
+// VAR bit 0: when no lane of the wave can produce a NaN in a slab product (o, d, 1/d all finite -- wave-uniform
+//            test via __all), the select chains of the slab test collapse to v_min/v_max, which give the same
+//            decisions (they differ only in the sign of a zero);
+// VAR bit 1: "while-while" control flow: lanes run inner nodes until each holds a leaf (or is done), then the
+//            wave does the leaves together -- same per-lane visiting order, better SIMD utilisation in the
+//            triangle loop.
 // ---------------------------------------------------------------------------------------------------
-template <bool EXACT, bool ANY, bool STATS>
+struct Lane {
+    float best_t, best_b, best_g;
+    int best_pos;
+    int sp, cur;
+    bool have;
+};
+
+// One 64-byte node record through the scalar data cache: when every active lane of the wave sits at the same
+// node (coherent camera / shadow rays near the top of the tree), one s_load_dwordx16 replaces 64 lanes x 4
+// global_load_dwordx4 -- the vector L1 (64 B/clk/CU) is what bounds this kernel (profiles/r01_pmc_sq.txt).
+typedef float v16f __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ v16f load_node_scalar(const float4 *nodes, int cur_uniform) {
+    const float4 *ptr = nodes + 4 * (size_t)cur_uniform;
+    v16f v;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ptr) : "memory");
+    return v;
+}
+
+template <bool EXACT, bool STATS, int SLAB>
+__device__ __forceinline__ void node_slabs(const float4 q0, const float4 q1, const float4 q2, const RayRegs &r,
+                                           float &mn0, float &mx0, float &mn1, float &mx1);
+
+// the post-test bookkeeping of BVH.cpp:609-651: near child first (ties -> child 0), far child pushed, else pop
+template <bool STATS>
+__device__ __forceinline__ void node_decide(float mn0, float mx0, float mn1, float mx1, int ref0, int ref1,
+                                            const RayRegs &r, Lane &L, int *s_stack, int tid, Stats &st) {
+    // tMax of this call == best_t: nothing changed since the node was entered
+    const bool h0 = !((mn0 > mx0) || (mn0 > L.best_t) || (mx0 < r.tmin));
+    const bool h1 = !((mn1 > mx1) || (mn1 > L.best_t) || (mx1 < r.tmin));
+    const bool one_first = h1 && (!h0 || (mn0 > mn1));
+    if (h0 && h1) {
+        s_stack[L.sp * kBlock + tid] = one_first ? ref0 : ref1;
+        L.sp++;
+        L.cur = one_first ? ref1 : ref0;
+        if (STATS) st.box++;
+    } else if (h0 || h1) {
+        L.cur = h0 ? ref0 : ref1;
+        if (STATS) st.box++;
+    } else if (L.sp > 0) {
+        L.sp--;
+        L.cur = s_stack[L.sp * kBlock + tid];
+        if (STATS) st.box++;                  // the far child is entered unconditionally (:640-650)
+    } else {
+        L.have = false;
+    }
+}
+
+// SLAB: 0 = select form (the reference's NaN semantics), 1 = min/max on (corner - o) * (1/d), 2 = lean fma form
+// SCALAR: try the wave-uniform scalar-load path first
+template <bool EXACT, bool STATS, int SLAB, bool SCALAR = false>
+__device__ __forceinline__ void node_step(const TraceParams &p, const RayRegs &r, Lane &L, int *s_stack, int tid, Stats &st) {
+    float mn0, mx0, mn1, mx1;
+    if (SCALAR) {
+        const int cur0 = __builtin_amdgcn_readfirstlane(L.cur);
+        if (__all(L.cur == cur0)) {
+            const v16f v = load_node_scalar(p.nodes, cur0);
+            node_slabs<EXACT, STATS, SLAB>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]),
+                                           make_float4(v[8], v[9], v[10], v[11]), r, mn0, mx0, mn1, mx1);
+            node_decide<STATS>(mn0, mx0, mn1, mx1, __float_as_int(v[12]), __float_as_int(v[13]), r, L, s_stack, tid, st);
+            return;
+        }
+    }
+    // ---- inner node: test both children (BVH.cpp:593-624)
+    const float4 *nd = p.nodes + 4 * (size_t)L.cur;
+    const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2];
+    const int4 q3 = *reinterpret_cast<const int4 *>(nd + 3);
+    node_slabs<EXACT, STATS, SLAB>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
+    node_decide<STATS>(mn0, mx0, mn1, mx1, q3.x, q3.y, r, L, s_stack, tid, st);
+}
+
+template <bool EXACT, bool STATS, int SLAB>
+__device__ __forceinline__ void node_slabs(const float4 q0, const float4 q1, const float4 q2, const RayRegs &r,
+                                           float &mn0, float &mx0, float &mn1, float &mx1) {
+    mn0 = -kInf; mx0 = kInf; mn1 = -kInf; mx1 = kInf;
+    if (SLAB == 2) {
+        slab_box_lean(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, r, mn0, mx0);
+        slab_box_lean(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, r, mn1, mx1);
+    } else if (EXACT && SLAB == 0) {
+        slab_axis<STATS>(q0.x, q0.y, r.ox, r.dx, r.ix, mn0, mx0);
+        slab_axis<STATS>(q0.z, q0.w, r.oy, r.dy, r.iy, mn0, mx0);
+        slab_axis<STATS>(q2.x, q2.y, r.oz, r.dz, r.iz, mn0, mx0);
+        slab_axis<STATS>(q1.x, q1.y, r.ox, r.dx, r.ix, mn1, mx1);
+        slab_axis<STATS>(q1.z, q1.w, r.oy, r.dy, r.iy, mn1, mx1);
+        slab_axis<STATS>(q2.z, q2.w, r.oz, r.dz, r.iz, mn1, mx1);
+    } else {
+        slab_axis_fast(q0.x, q0.y, r.ox, r.ix, mn0, mx0);
+        slab_axis_fast(q0.z, q0.w, r.oy, r.iy, mn0, mx0);
+        slab_axis_fast(q2.x, q2.y, r.oz, r.iz, mn0, mx0);
+        slab_axis_fast(q1.x, q1.y, r.ox, r.ix, mn1, mx1);
+        slab_axis_fast(q1.z, q1.w, r.oy, r.iy, mn1, mx1);
+        slab_axis_fast(q2.z, q2.w, r.oz, r.iz, mn1, mx1);
+    }
+}
+
+// one 48-byte triangle record through the scalar data cache (all active lanes at the same leaf)
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load_tri_scalar(const float4 *tris, unsigned pos_uniform, float4 &q0, float4 &q1, float4 &q2) {
+    const float4 *ptr = tris + 3 * (size_t)pos_uniform;
+    v4f a, b, c;
+    asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b), "=&s"(c) : "s"(ptr) : "memory");
+    q0 = make_float4(a[0], a[1], a[2], a[3]);
+    q1 = make_float4(b[0], b[1], b[2], b[3]);
+    q2 = make_float4(c[0], c[1], c[2], c[3]);
+}
+
+template <bool EXACT, bool ANY, bool STATS, bool SCALAR = false>
+__device__ __forceinline__ void leaf_step(const TraceParams &p, const RayRegs &r, Lane &L, int *s_stack, int tid, Stats &st) {
+    // ---- leaf (BVH.cpp:493-509)
+    const unsigned bits = ~(unsigned)L.cur;
+    const unsigned first = bits >> kLeafCountBits;
+    unsigned cnt = bits & kLeafCountMask;
+    if (cnt == kLeafCountMask) cnt = p.leaf_cnt_ext[first];
+    bool done = false;
+    bool uniform = false;
+    if (SCALAR) {
+        const int cur0 = __builtin_amdgcn_readfirstlane(L.cur);
+        uniform = __all(L.cur == cur0);
+        if (uniform) {
+            const unsigned first0 = (unsigned)__builtin_amdgcn_readfirstlane((int)first);
+            const unsigned cnt0 = (unsigned)__builtin_amdgcn_readfirstlane((int)cnt);
+            for (unsigned k = 0; k < cnt0; k++) {
+                float4 q0, q1, q2;
+                load_tri_scalar(p.tris, first0 + k, q0, q1, q2);
+                if (!(ANY && done)) {
+                    float t, b, g;
+                    const bool ok = tri_test<EXACT>(q0, q1, q2, r, L.best_t, t, b, g);
+                    if (ok && t < L.best_t) {
+                        L.best_t = t; L.best_b = b; L.best_g = g; L.best_pos = (int)(first0 + k);
+                        if (ANY) done = true;
+                    }
+                }
+            }
+        }
+    }
+    if (!uniform) {
+        for (unsigned k = 0; k < cnt; k++) {
+            const float4 *tr = p.tris + 3 * (size_t)(first + k);
+            float t, b, g;
+            const bool ok = tri_test<EXACT>(tr[0], tr[1], tr[2], r, L.best_t, t, b, g);
+            if (ok && t < L.best_t) {             // strict-less replacement (:500)
+                L.best_t = t; L.best_b = b; L.best_g = g; L.best_pos = (int)(first + k);
+                if (ANY) { done = true; break; }
+            }
+        }
+    }
+    if (STATS) st.tri += cnt;
+    if (ANY && done) {
+        L.have = false;
+    } else if (L.sp > 0) {
+        L.sp--;
+        L.cur = s_stack[L.sp * kBlock + tid];
+        if (STATS) st.box++;
+    } else {
+        L.have = false;
+    }
+}
+
+template <bool EXACT, bool ANY, bool STATS, int SLAB, bool WW, bool SCALAR>
+__device__ __forceinline__ void traverse(const TraceParams &p, const RayRegs &r, Lane &L, int *s_stack, int tid, Stats &st) {
+    if (WW) {
+        while (__any(L.have)) {
+            while (L.have && L.cur >= 0) node_step<EXACT, STATS, SLAB, SCALAR>(p, r, L, s_stack, tid, st);
+            if (L.have) leaf_step<EXACT, ANY, STATS, SCALAR>(p, r, L, s_stack, tid, st);
+        }
+    } else {
+        while (L.have) {
+            if (L.cur >= 0) node_step<EXACT, STATS, SLAB, SCALAR>(p, r, L, s_stack, tid, st);
+            else leaf_step<EXACT, ANY, STATS, false>(p, r, L, s_stack, tid, st);
+        }
+    }
+}
+
+template <bool EXACT, bool ANY, bool STATS, int VAR>
 __global__ __launch_bounds__(kBlock) void trace_kernel(TraceParams p) {
     extern __shared__ int s_stack[];                  // [stack_depth][kBlock]
     const int tid = threadIdx.x;
     const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
     Stats st = {0ull, 0ull};
+    constexpr bool kMinMax = !STATS && (VAR & 1);
+    constexpr bool kWW = (VAR & 2) != 0;
+    constexpr int kSafeSlab = (VAR & 4) ? 2 : 1;      // slab form for waves whose rays cannot produce a NaN
+    constexpr bool kScalar = (VAR & 8) != 0;          // wave-uniform nodes through the scalar cache
 
     // indirect batches: the ray count lives on the device (e.g. written by the shadow-ray compaction)
     unsigned long long n_rays = p.n;
     if (p.n_dev) { const unsigned long long nd = *p.n_dev; if (nd < n_rays) n_rays = nd; }
+    const unsigned long long n_round = kWW ? ((n_rays + 63ull) & ~63ull) : n_rays;   // whole waves for __any
 
-    for (unsigned long long idx = (unsigned long long)blockIdx.x * kBlock + tid; idx < n_rays; idx += stride) {
+    for (unsigned long long idx = (unsigned long long)blockIdx.x * kBlock + tid; idx < n_round; idx += stride) {
+        const bool live = idx < n_rays;
         // two dwordx4 loads per lane, 32-byte stride: every byte of the fetched lines is used
-        const float4 ra = reinterpret_cast<const float4 *>(p.rays)[2 * idx];
-        const float4 rb = reinterpret_cast<const float4 *>(p.rays)[2 * idx + 1];
+        float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(1.f, 1.f, 1.f, -1.f);
+        if (live) {
+            ra = reinterpret_cast<const float4 *>(p.rays)[2 * idx];
+            rb = reinterpret_cast<const float4 *>(p.rays)[2 * idx + 1];
+        }
         RayRegs r;
-        r.ox = ra.x; r.oy = ra.y; r.oz = ra.z; r.tmin = ra.w;
-        r.dx = rb.x; r.dy = rb.y; r.dz = rb.z;
+        ray_setup(r, ra, rb);
         const float tmax0 = rb.w;
-        r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
-        r.mx_ = -r.dx; r.my_ = -r.dy; r.mz_ = -r.dz;
 
-        float best_t = tmax0;                         // minHit.t = tMax (BVH.cpp:444)
-        float best_b = 0.0f, best_g = 0.0f;
-        int best_pos = -1;                            // leaf-order position of the winning triangle
-
-        int sp = 0;                                   // entries of this lane on the LDS stack
-        int cur;
-        bool have;
+        Lane L;
+        L.best_t = tmax0;                             // minHit.t = tMax (BVH.cpp:444)
+        L.best_b = 0.0f; L.best_g = 0.0f;
+        L.best_pos = -1;                              // leaf-order position of the winning triangle
+        L.sp = 0;                                     // entries of this lane on the LDS stack
         {   // BVH::intersect root test (BVH.cpp:447-466)
             float mn = -kInf, mx = kInf;
             slab_axis<STATS>(p.root_lo[0], p.root_hi[0], r.ox, r.dx, r.ix, mn, mx);
             slab_axis<STATS>(p.root_lo[1], p.root_hi[1], r.oy, r.dy, r.iy, mn, mx);
             slab_axis<STATS>(p.root_lo[2], p.root_hi[2], r.oz, r.dz, r.iz, mn, mx);
-            if (STATS) st.box++;
-            have = !((mn > mx) || (mn > tmax0) || (mx < r.tmin));
-            cur = p.root_ref;
+            if (STATS && live) st.box++;
+            L.have = live && !((mn > mx) || (mn > tmax0) || (mx < r.tmin));
+            L.cur = p.root_ref;
         }
 
-        while (have) {
-            if (cur >= 0) {
-                // ---- inner node: test both children (BVH.cpp:593-624)
-                const float4 *nd = p.nodes + 4 * (size_t)cur;
-                const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2];
-                const int4 q3 = *reinterpret_cast<const int4 *>(nd + 3);
-                float mn0 = -kInf, mx0 = kInf, mn1 = -kInf, mx1 = kInf;
-                if (EXACT) {
-                    slab_axis<STATS>(q0.x, q0.y, r.ox, r.dx, r.ix, mn0, mx0);
-                    slab_axis<STATS>(q0.z, q0.w, r.oy, r.dy, r.iy, mn0, mx0);
-                    slab_axis<STATS>(q2.x, q2.y, r.oz, r.dz, r.iz, mn0, mx0);
-                    slab_axis<STATS>(q1.x, q1.y, r.ox, r.dx, r.ix, mn1, mx1);
-                    slab_axis<STATS>(q1.z, q1.w, r.oy, r.dy, r.iy, mn1, mx1);
-                    slab_axis<STATS>(q2.z, q2.w, r.oz, r.dz, r.iz, mn1, mx1);
-                } else {
-                    slab_axis_fast(q0.x, q0.y, r.ox, r.ix, mn0, mx0);
-                    slab_axis_fast(q0.z, q0.w, r.oy, r.iy, mn0, mx0);
-                    slab_axis_fast(q2.x, q2.y, r.oz, r.iz, mn0, mx0);
-                    slab_axis_fast(q1.x, q1.y, r.ox, r.ix, mn1, mx1);
-                    slab_axis_fast(q1.z, q1.w, r.oy, r.iy, mn1, mx1);
-                    slab_axis_fast(q2.z, q2.w, r.oz, r.iz, mn1, mx1);
-                }
-                // tMax of this call == best_t: nothing changed since the node was entered
-                const bool h0 = !((mn0 > mx0) || (mn0 > best_t) || (mx0 < r.tmin));
-                const bool h1 = !((mn1 > mx1) || (mn1 > best_t) || (mx1 < r.tmin));
-                // near-first; on equal entry distance child 0 goes first (:612-623)
-                const bool one_first = h1 && (!h0 || (mn0 > mn1));
-                if (h0 && h1) {
-                    s_stack[sp * kBlock + tid] = one_first ? q3.x : q3.y;
-                    sp++;
-                    cur = one_first ? q3.y : q3.x;
-                    if (STATS) st.box++;
-                } else if (h0 || h1) {
-                    cur = h0 ? q3.x : q3.y;
-                    if (STATS) st.box++;
-                } else if (sp > 0) {
-                    sp--;
-                    cur = s_stack[sp * kBlock + tid];
-                    if (STATS) st.box++;              // the far child is entered unconditionally (:640-650)
-                } else {
-                    have = false;
-                }
-            } else {
-                // ---- leaf (BVH.cpp:493-509)
-                const unsigned bits = ~(unsigned)cur;
-                const unsigned first = bits >> kLeafCountBits;
-                unsigned cnt = bits & kLeafCountMask;
-                if (cnt == kLeafCountMask) cnt = p.leaf_cnt_ext[first];
-                bool done = false;
-                for (unsigned k = 0; k < cnt; k++) {
-                    const float4 *tr = p.tris + 3 * (size_t)(first + k);
-                    float t, b, g;
-                    const bool ok = tri_test<EXACT>(tr[0], tr[1], tr[2], r, best_t, t, b, g);
-                    if (ok && t < best_t) {           // strict-less replacement (:500)
-                        best_t = t; best_b = b; best_g = g; best_pos = (int)(first + k);
-                        if (ANY) { done = true; break; }
-                    }
-                }
-                if (STATS) st.tri += cnt;
-                if (ANY && done) {
-                    have = false;
-                } else if (sp > 0) {
-                    sp--;
-                    cur = s_stack[sp * kBlock + tid];
-                    if (STATS) st.box++;
-                } else {
-                    have = false;
-                }
-            }
-        }
-
-        mr_hit h;
-        if (best_pos >= 0) {
-            h.t = best_t; h.prim = p.tri_prim[best_pos]; h.beta = best_b; h.gamma = best_g;
+        if (kMinMax) {
+            // a slab product (corner - o) * (1/d) can only be NaN as 0*inf or inf*0 or from a non-finite origin:
+            // with o, d and 1/d all finite in every lane the select form and the min/max form decide identically
+            if (__all(lane_is_nan_free(r) || !live)) traverse<EXACT, ANY, STATS, kSafeSlab, kWW, kScalar>(p, r, L, s_stack, tid, st);
+            else traverse<EXACT, ANY, STATS, 0, kWW, false>(p, r, L, s_stack, tid, st);
         } else {
-            h.t = tmax0; h.prim = MR_MISS; h.beta = 0.0f; h.gamma = 0.0f;
+            traverse<EXACT, ANY, STATS, 0, kWW, false>(p, r, L, s_stack, tid, st);
         }
-        reinterpret_cast<float4 *>(p.hits)[idx] = *reinterpret_cast<const float4 *>(&h);
+
+        if (live) {
+            mr_hit h;
+            if (L.best_pos >= 0) {
+                h.t = L.best_t; h.prim = p.tri_prim[L.best_pos]; h.beta = L.best_b; h.gamma = L.best_g;
+            } else {
+                h.t = tmax0; h.prim = MR_MISS; h.beta = 0.0f; h.gamma = 0.0f;
+            }
+            reinterpret_cast<float4 *>(p.hits)[idx] = *reinterpret_cast<const float4 *>(&h);
+        }
     }
 
     if (STATS) {
@@ -224,6 +397,95 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(TraceParams p) {
             atomicAdd(&p.stats[0], st.box);
             atomicAdd(&p.stats[1], st.tri);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Persistent form for incoherent batches (secondary / shadow / random rays): a resident grid of waves pulls
+// rays from a global counter.  Whenever at least REFILL_MIN lanes of a wave have finished their ray, the wave
+// ballots the idle lanes, retires their hits, and re-arms them with fresh rays by prefix-sum over the ballot
+// (wave64 active-ray compaction: lanes never wait for the slowest ray of a fixed group of 64).  Rays are handed
+// out from a wave-local pool of kPoolChunk consecutive indices so that the global counter sees one atomic per
+// chunk.  Per-ray work and results are those of trace_kernel.
+// ---------------------------------------------------------------------------------------------------
+constexpr unsigned long long kPoolChunk = 1024;
+constexpr int kPersistentSafeSlab = 1;    // same slab arithmetic as the default kernel (bit-identical results)
+
+template <bool EXACT, bool ANY, int REFILL_MIN>
+__global__ __launch_bounds__(kBlock) void trace_persistent_kernel(TraceParams p, unsigned long long *next_ray) {
+    extern __shared__ int s_stack[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    Stats st = {0ull, 0ull};
+    unsigned long long n_rays = p.n;
+    if (p.n_dev) { const unsigned long long nd = *p.n_dev; if (nd < n_rays) n_rays = nd; }
+
+    unsigned long long pool_next = 0, pool_end = 0;      // wave-uniform
+    bool exhausted = false;                              // wave-uniform
+    const unsigned long long kNone = ~0ull;
+    unsigned long long my_idx = kNone;
+    float tmax0 = 0.0f;
+    bool safe_lane = true;
+    RayRegs r = {};
+    Lane L;
+    L.best_t = 0.f; L.best_b = 0.f; L.best_g = 0.f; L.best_pos = -1; L.sp = 0; L.cur = 0; L.have = false;
+
+    while (true) {
+        const unsigned long long idle = __ballot(!L.have);
+        const int n_idle = __popcll(idle);
+        if (n_idle >= REFILL_MIN || idle == ~0ull) {
+            // retire the rays of the idle lanes
+            if (!L.have && my_idx != kNone) {
+                mr_hit h;
+                if (L.best_pos >= 0) { h.t = L.best_t; h.prim = p.tri_prim[L.best_pos]; h.beta = L.best_b; h.gamma = L.best_g; }
+                else { h.t = tmax0; h.prim = MR_MISS; h.beta = 0.0f; h.gamma = 0.0f; }
+                reinterpret_cast<float4 *>(p.hits)[my_idx] = *reinterpret_cast<const float4 *>(&h);
+                my_idx = kNone;
+            }
+            if (pool_next == pool_end && !exhausted) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(next_ray, kPoolChunk);
+                base = __shfl(base, 0, 64);
+                if (base >= n_rays) { exhausted = true; pool_next = pool_end = 0; }
+                else { pool_next = base; pool_end = base + kPoolChunk < n_rays ? base + kPoolChunk : n_rays; }
+            }
+            if (pool_next < pool_end) {
+                const unsigned long long cand = pool_next + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+                if (!L.have && cand < pool_end) {
+                    my_idx = cand;
+                    const float4 ra = reinterpret_cast<const float4 *>(p.rays)[2 * cand];
+                    const float4 rb = reinterpret_cast<const float4 *>(p.rays)[2 * cand + 1];
+                    ray_setup(r, ra, rb);
+                    tmax0 = rb.w;
+                    L.best_t = tmax0; L.best_b = 0.0f; L.best_g = 0.0f; L.best_pos = -1; L.sp = 0;
+                    float mn = -kInf, mx = kInf;
+                    slab_axis<false>(p.root_lo[0], p.root_hi[0], r.ox, r.dx, r.ix, mn, mx);
+                    slab_axis<false>(p.root_lo[1], p.root_hi[1], r.oy, r.dy, r.iy, mn, mx);
+                    slab_axis<false>(p.root_lo[2], p.root_hi[2], r.oz, r.dz, r.iz, mn, mx);
+                    L.have = !((mn > mx) || (mn > tmax0) || (mx < r.tmin));
+                    L.cur = p.root_ref;
+                    safe_lane = lane_is_nan_free(r);
+                }
+                const unsigned long long adv = pool_next + (unsigned)n_idle;
+                pool_next = adv < pool_end ? adv : pool_end;
+            }
+        }
+        if (!__any(L.have)) {
+            if (exhausted && pool_next == pool_end) {
+                if (my_idx != kNone) {              // rays that missed the root box in the last hand-out
+                    mr_hit h;
+                    h.t = tmax0; h.prim = MR_MISS; h.beta = 0.0f; h.gamma = 0.0f;
+                    reinterpret_cast<float4 *>(p.hits)[my_idx] = *reinterpret_cast<const float4 *>(&h);
+                }
+                break;
+            }
+            continue;
+        }
+        if (__all(safe_lane || !L.have)) {
+            while (L.have && L.cur >= 0) node_step<EXACT, false, kPersistentSafeSlab, true>(p, r, L, s_stack, tid, st);
+        } else {
+            while (L.have && L.cur >= 0) node_step<EXACT, false, 0>(p, r, L, s_stack, tid, st);
+        }
+        if (L.have) leaf_step<EXACT, ANY, false, true>(p, r, L, s_stack, tid, st);
     }
 }
 
@@ -383,29 +645,79 @@ inline unsigned grid_for(unsigned long long n) {
     return (unsigned)blocks;
 }
 
-template <bool EXACT, bool ANY, bool STATS>
+template <bool EXACT, bool ANY, bool STATS, int VAR>
 mr_status launch_trace_t(const TraceParams &p, hipStream_t stream) {
     const size_t lds = (size_t)p.stack_depth * kBlock * sizeof(int);
     if (lds > 160 * 1024) return fail(MR_ERR_INVALID, "traversal stack of depth %d does not fit in LDS", p.stack_depth);
     if (lds > 64 * 1024)
-        MR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&trace_kernel<EXACT, ANY, STATS>),
+        MR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&trace_kernel<EXACT, ANY, STATS, VAR>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((trace_kernel<EXACT, ANY, STATS>), dim3(grid_for(p.n)), dim3(kBlock), lds, stream, p);
+    hipLaunchKernelGGL((trace_kernel<EXACT, ANY, STATS, VAR>), dim3(grid_for(p.n)), dim3(kBlock), lds, stream, p);
     MR_HIP_CHECK(hipGetLastError());
     return MR_OK;
 }
 
 }  // namespace
 
+// development switch: MIRO_TRACE_VARIANT selects the control-flow / slab-test variant of the exact kernel:
+//   0..15  one launch-time ray per lane (bit 0: min/max slabs, bit 1: while-while, bit 2: lean fma slabs,
+//          bit 3: wave-uniform nodes through the scalar cache)
+//   16,17  persistent waves with ballot/prefix re-arming of idle lanes (refill threshold 1 / 16 lanes)
+static int trace_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("MIRO_TRACE_VARIANT");
+        v = e ? (atoi(e) & 31) : kDefaultVariant;
+    }
+    return v;
+}
+
+template <bool EXACT, bool ANY, int REFILL_MIN>
+static mr_status launch_persistent(const TraceParams &p, hipStream_t stream) {
+    const size_t lds = (size_t)p.stack_depth * kBlock * sizeof(int);
+    if (lds > 160 * 1024) return fail(MR_ERR_INVALID, "traversal stack of depth %d does not fit in LDS", p.stack_depth);
+    auto kern = &trace_persistent_kernel<EXACT, ANY, REFILL_MIN>;
+    if (lds > 64 * 1024)
+        MR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int dev = 0, cus = 256, per_cu = 1;
+    MR_HIP_CHECK(hipGetDevice(&dev));
+    MR_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    MR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), kBlock, lds));
+    if (per_cu < 1) per_cu = 1;
+    unsigned long long want = (p.n + kBlock - 1) / kBlock;
+    unsigned long long grid = (unsigned long long)cus * (unsigned)per_cu;
+    if (want < grid) grid = want;
+    MR_HIP_CHECK(hipMemsetAsync(p.work_counter, 0, sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds, stream, p, p.work_counter);
+    MR_HIP_CHECK(hipGetLastError());
+    return MR_OK;
+}
+
+template <bool ANY>
+static mr_status launch_exact(const TraceParams &p, hipStream_t stream) {
+    switch (trace_variant()) {
+        case 0: return launch_trace_t<true, ANY, false, 0>(p, stream);
+        case 1: return launch_trace_t<true, ANY, false, 1>(p, stream);
+        case 2: return launch_trace_t<true, ANY, false, 2>(p, stream);
+        case 3: return launch_trace_t<true, ANY, false, 3>(p, stream);
+        case 7: return launch_trace_t<true, ANY, false, 7>(p, stream);
+        case 9: return launch_trace_t<true, ANY, false, 9>(p, stream);
+        case 16: return launch_persistent<true, ANY, 1>(p, stream);
+        case 17: return launch_persistent<true, ANY, 16>(p, stream);
+        default: return launch_trace_t<true, ANY, false, 11>(p, stream);
+    }
+}
+
 mr_status launch_trace(const TraceParams &p, uint32_t flags, hipStream_t stream) {
     if (p.n == 0) return MR_OK;
     const bool fast = flags & MR_MATH_FAST, any = flags & MR_TRACE_ANY, stats = flags & MR_COUNT_STATS;
     if (stats) {
-        // counting mode is diagnostic: always the strict-division exact kernel
-        return any ? launch_trace_t<true, true, true>(p, stream) : launch_trace_t<true, false, true>(p, stream);
+        // counting mode is diagnostic: always the strict-division exact kernel in the reference's control flow
+        return any ? launch_trace_t<true, true, true, 0>(p, stream) : launch_trace_t<true, false, true, 0>(p, stream);
     }
-    if (fast) return any ? launch_trace_t<false, true, false>(p, stream) : launch_trace_t<false, false, false>(p, stream);
-    return any ? launch_trace_t<true, true, false>(p, stream) : launch_trace_t<true, false, false>(p, stream);
+    if (fast) return any ? launch_trace_t<false, true, false, 7>(p, stream) : launch_trace_t<false, false, false, 7>(p, stream);
+    if (flags & MR_TRACE_PERSISTENT) return any ? launch_persistent<true, true, 16>(p, stream) : launch_persistent<true, false, 16>(p, stream);
+    return any ? launch_exact<true>(p, stream) : launch_exact<false>(p, stream);
 }
 
 mr_status launch_eye_rays(const mr_camera &cam, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,

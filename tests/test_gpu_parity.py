@@ -159,6 +159,22 @@ def test_degenerate_scenes(oracle, miro, torch_cuda):
         assert b.stats() == stats_want
 
 
+@pytest.mark.parametrize("name", ["teapot", "sponza"])
+def test_persistent_kernel_bit_exact(oracle, miro, torch_cuda, name):
+    """MR_TRACE_PERSISTENT (resident waves, ballot/prefix re-arming of idle lanes) returns exactly what the
+    one-ray-per-lane kernel returns: incoherent rays, a ragged count, closest and any-hit."""
+    a, b = both(oracle, miro, name)
+    lo, hi = scene_box(a)
+    rays = random_rays(oracle.RAY_DTYPE, 50021, np.maximum(lo, -20), np.minimum(hi, 20), seed=31)
+    want = a.trace(rays)
+    assert_hits_bit_exact(b.trace(rays.view(miro.RAY_DTYPE), miro.MR_TRACE_PERSISTENT), want.view(miro.HIT_DTYPE))
+    for n in (1, 63, 65, 1023, 1025):
+        assert_hits_bit_exact(b.trace(rays[:n].view(miro.RAY_DTYPE), miro.MR_TRACE_PERSISTENT), want[:n].view(miro.HIT_DTYPE))
+    any_a = b.trace(rays.view(miro.RAY_DTYPE), miro.MR_TRACE_ANY)
+    any_b = b.trace(rays.view(miro.RAY_DTYPE), miro.MR_TRACE_ANY | miro.MR_TRACE_PERSISTENT)
+    assert_hits_bit_exact(any_b, any_a)
+
+
 # ----------------------------------------------------------------------------------------------- counters
 @pytest.mark.parametrize("name", ["teapot", "bunny"])
 def test_stats_counters_match_reference(oracle, miro, torch_cuda, golden_dir, name):

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--spp", type=int, default=4)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--leaf", type=int, default=4)
+    ap.add_argument("--incoherent", type=int, default=0, help="also time this many random rays")
+    ap.add_argument("--no-host", action="store_true")
     a = ap.parse_args()
     stream = torch.cuda.current_stream()
     for name in a.scenes:
@@ -60,6 +62,33 @@ def main():
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / a.reps
                 print("  %-5s %-10s %8.3f ms  %9.1f Mrays/s" % (label, what, ms, cnt / ms / 1e3))
+        if a.incoherent:
+            # incoherent batch: random origins inside the scene box, uniform directions (divergent traversal)
+            v = sc.arrays()[0]
+            lo, hi = np.maximum(v.min(0), -20), np.minimum(v.max(0), 20)
+            g = torch.Generator(device="cuda").manual_seed(7)
+            m = a.incoherent
+            o = torch.rand((m, 3), device="cuda", generator=g) * torch.tensor(hi - lo, device="cuda") + torch.tensor(lo, device="cuda")
+            dd = torch.randn((m, 3), device="cuda", generator=g)
+            dd = dd / dd.norm(dim=1, keepdim=True)
+            r = torch.zeros((m, 8), device="cuda")
+            r[:, 0:3] = o
+            r[:, 4:7] = dd
+            r[:, 7] = 1e12
+            hh = torch.empty((m, 4), device="cuda")
+            for label, flags in (("exact", 0), ("fast", miro_amd.MR_MATH_FAST)):
+                sc.trace_device(r, m, hh, flags, stream=stream)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(a.reps):
+                    sc.trace_device(r, m, hh, flags, stream=stream)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / a.reps
+                print("  %-5s %-10s %8.3f ms  %9.1f Mrays/s" % (label, "incoherent", ms, m / ms / 1e3))
+        if a.no_host:
+            sc.close()
+            continue
         # PCIe-inclusive rate of the host-buffer form of mr_trace (pageable numpy arrays, staged by the library)
         h_rays = d_rays.cpu().numpy().view(miro_amd.RAY_DTYPE).reshape(-1)
         sc.trace(h_rays[:1024])
