@@ -114,6 +114,17 @@ mr_status launch_shade(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit
                        hipStream_t stream);
 mr_status launch_tonemap(const float *d_rgb, unsigned long long n_values, uint8_t *d_out, hipStream_t stream);
 
+// photon map on the device: three float4 planes in kd-tree heap order, 1-based (children of i: 2i, 2i+1)
+struct PhotonMapDev {
+    float4 *posplane = nullptr;   // (x, y, z, split axis as int bits)
+    float4 *dir = nullptr;        // incoming direction de-quantised through the reference's tables
+    float4 *power = nullptr;      // (r, g, b, -)
+    int32_t n = 0, half = 0;      // stored photons; nodes with index < half descend (PhotonMap.cpp:160,357)
+};
+constexpr int kKnnMaxK = 512;     // nphotons limit of the wave-cooperative k-NN (PHOTON_SAMPLES = 500)
+mr_status launch_irradiance(const PhotonMapDev &pm, const float *d_pos, const float *d_normal, unsigned long long nq,
+                            float max_dist, uint32_t k, float *d_irrad, int32_t *d_found, float *d_r2, hipStream_t stream);
+
 }  // namespace mr
 
 struct mr_scene {

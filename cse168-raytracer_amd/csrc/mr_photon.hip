@@ -1,0 +1,218 @@
+// mr_photon.hip -- Photon_map::irradiance_estimate / locate_photons (PhotonMap.cpp:81-243) on gfx950:
+// one wave64 per query, the k-nearest candidate set in LDS.
+//
+// The reference walks the implicit kd-tree one node at a time with a 500-entry max-heap per query.  Here a wave
+// takes a *block* of the heap-ordered tree per step: the 63 nodes of six consecutive levels below a block root b
+// are b*2^l + o (contiguous per level, so the loads coalesce), one node per lane.  Every lane decides whether its
+// node is reachable under the reference's pruning rule (near side always, far side only if the splitting plane is
+// closer than the current search radius) by pulling its ancestors' decisions from their lanes (__shfl), tests its
+// photon (distance, facing), and accepted photons are appended to the LDS candidate buffer by ballot + prefix sum.
+// Level-5 lanes push their reachable children as new block roots (far children first, so near ones pop first).
+// When the buffer is nearly full the wave selects the k smallest distances (4-pass radix select on the float bits,
+// LDS histogram) and the k-th becomes the new radius -- the same radius the reference's heap would hold after
+// seeing those photons, applied lazily, so a superset of nodes is visited and the same k photons survive.
+//
+// Kept from the reference: nodes with index >= stored/2-1 do not descend; the normalising radius stays
+// max_dist^2 unless more than k candidates were seen; strict comparisons.  Not kept: the order in which powers
+// are summed (float rounding, ~1e-6 relative) and the reference's first-overflow replacement, which may trade one
+// boundary photon.
+#include <hip/hip_runtime.h>
+
+#include "mr_internal.h"
+
+namespace mr {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+constexpr int kCap = 1024;         // candidate slots per wave
+constexpr int kStack = 512;        // pending block roots per wave
+
+struct WaveLds {
+    float d2[kCap];
+    int idx[kCap];
+    int stack[kStack];
+    unsigned hist[256];
+};
+
+// k-th smallest (1-based rank `k`) of d2[0..count): returns its bit pattern and how many entries equal to it belong
+// to the k smallest.  Non-negative floats order like their bit patterns.
+__device__ __forceinline__ unsigned radix_select(WaveLds &w, int count, int k, int lane, int &eq_keep) {
+    unsigned prefix = 0;
+    int remaining = k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int b = lane; b < 256; b += 64) w.hist[b] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        for (int i = lane; i < count; i += 64) {
+            const unsigned key = __float_as_uint(w.d2[i]);
+            const bool in = shift == 24 || (key >> (shift + 8)) == (prefix >> (shift + 8));
+            if (in) atomicAdd(&w.hist[(key >> shift) & 255u], 1u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // lane holds bins 4*lane .. 4*lane+3
+        const unsigned h0 = w.hist[4 * lane], h1 = w.hist[4 * lane + 1], h2 = w.hist[4 * lane + 2], h3 = w.hist[4 * lane + 3];
+        const int local = (int)(h0 + h1 + h2 + h3);
+        int incl = local;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        const unsigned long long m = __ballot(incl >= remaining);
+        const int tl = __ffsll((long long)m) - 1;            // first lane whose cumulative count reaches the rank
+        int bin = 0, before = 0;
+        if (lane == tl) {
+            int c = incl - local;
+            if (c + (int)h0 >= remaining) { bin = 4 * lane; before = c; }
+            else if (c + (int)(h0 + h1) >= remaining) { bin = 4 * lane + 1; before = c + (int)h0; }
+            else if (c + (int)(h0 + h1 + h2) >= remaining) { bin = 4 * lane + 2; before = c + (int)(h0 + h1); }
+            else { bin = 4 * lane + 3; before = c + (int)(h0 + h1 + h2); }
+        }
+        bin = __shfl(bin, tl, 64);
+        before = __shfl(before, tl, 64);
+        prefix |= (unsigned)bin << shift;
+        remaining -= before;
+    }
+    eq_keep = remaining;
+    return prefix;
+}
+
+// keep the k smallest candidates at the front of the buffer; returns the k-th distance
+__device__ __forceinline__ float compress(WaveLds &w, int &count, int k, int lane) {
+    int eq_keep;
+    const unsigned kth = radix_select(w, count, k, lane, eq_keep);
+    int out = 0, eq_seen = 0;
+    for (int base = 0; base < count; base += 64) {
+        const int i = base + lane;
+        float d = 0.0f;
+        int id = 0;
+        bool lt = false, eq = false;
+        if (i < count) {
+            d = w.d2[i]; id = w.idx[i];
+            const unsigned key = __float_as_uint(d);
+            lt = key < kth; eq = key == kth;
+        }
+        const unsigned long long meq = __ballot(eq);
+        const int eq_rank = eq_seen + __popcll(meq & ((1ull << lane) - 1ull));
+        const bool keep = lt || (eq && eq_rank < eq_keep);
+        const unsigned long long mk = __ballot(keep);
+        if (keep) {
+            const int pos = out + __popcll(mk & ((1ull << lane) - 1ull));
+            w.d2[pos] = d; w.idx[pos] = id;                  // pos <= i: never overtakes an unread slot
+        }
+        out += __popcll(mk);
+        eq_seen += __popcll(meq);
+    }
+    count = out;
+    return __uint_as_float(kth);
+}
+
+__global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, const float *qpos, const float *qnrm,
+                                                            unsigned long long nq, float max_dist, int k, float *irrad,
+                                                            int *found_out, float *r2_out) {
+    __shared__ WaveLds s_w[kWaves];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    WaveLds &w = s_w[wv];
+    const unsigned long long wave_id = (unsigned long long)blockIdx.x * kWaves + wv;
+    const unsigned long long n_waves = (unsigned long long)gridDim.x * kWaves;
+    // node of this lane inside a block: level lv (0..5), offset within the level
+    const int lv = 31 - __clz(lane + 1);
+    const int off_in_level = lane + 1 - (1 << lv);
+    const int parent_lane = ((lane + 1) >> 1) - 1;
+    const bool node_lane = lane < 63;
+
+    for (unsigned long long q = wave_id; q < nq; q += n_waves) {
+        const float qx = qpos[3 * q], qy = qpos[3 * q + 1], qz = qpos[3 * q + 2];
+        const float nx = qnrm[3 * q], ny = qnrm[3 * q + 1], nz = qnrm[3 * q + 2];
+        const float md2 = max_dist * max_dist;
+        float r2 = md2;                                       // np.dist2[0] (PhotonMap.cpp:99)
+        int count = 0;
+        bool evicted = false;
+        int sp = 0;
+        if (pm.n >= 1) { if (lane == 0) w.stack[0] = 1; sp = 1; }
+
+        while (sp > 0) {
+            sp--;
+            const int b = w.stack[sp];                        // same address in every lane: LDS broadcast
+            const long long jj = ((long long)b << lv) + off_in_level;
+            const bool valid = node_lane && jj <= (long long)pm.n;
+            const int j = valid ? (int)jj : 0;
+            float4 A = make_float4(0.f, 0.f, 0.f, 0.f), D = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) { A = pm.posplane[j]; D = pm.dir[j]; }
+            const int plane = __float_as_int(A.w);
+            const float pc = plane == 0 ? A.x : (plane == 1 ? A.y : A.z);
+            const float qc = plane == 0 ? qx : (plane == 1 ? qy : qz);
+            const float d1 = qc - pc;                         // :161
+            const bool desc = valid && j < pm.half;           // :160
+            // reachability inside the block, level by level
+            bool reach = valid && lv == 0;
+            for (int L = 1; L <= 5; L++) {
+                const int p_reach = __shfl((int)reach, parent_lane, 64);
+                const int p_desc = __shfl((int)desc, parent_lane, 64);
+                const float p_d1 = __shfl(d1, parent_lane, 64);
+                if (lv == L && valid) {
+                    const bool is_right = (j & 1) != 0, near_right = p_d1 > 0.0f;     // :163-172
+                    reach = p_reach && p_desc && (is_right == near_right || p_d1 * p_d1 < r2);
+                }
+            }
+            // the photon itself (:177-186)
+            float dd = A.x - qx;
+            float d2 = dd * dd;
+            dd = A.y - qy; d2 += dd * dd;
+            dd = A.z - qz; d2 += dd * dd;
+            const float facing = (D.x * nx + D.y * ny) + D.z * nz;
+            const bool cand = reach && d2 < r2 && facing < 0.0f;
+            const unsigned long long mc = __ballot(cand);
+            if (cand) {
+                const int pos = count + __popcll(mc & ((1ull << lane) - 1ull));
+                w.d2[pos] = d2; w.idx[pos] = j;
+            }
+            count += __popcll(mc);
+            // children of the level-5 nodes become block roots: far side first, near side last (popped first)
+            const bool can_push = valid && lv == 5 && reach && desc;
+            const int near_child = d1 > 0.0f ? 2 * j + 1 : 2 * j;
+            const int far_child = near_child ^ 1;
+            const bool push_far = can_push && far_child <= pm.n && d1 * d1 < r2;
+            const bool push_near = can_push && near_child <= pm.n;
+            const unsigned long long mf = __ballot(push_far);
+            if (push_far) w.stack[sp + __popcll(mf & ((1ull << lane) - 1ull))] = far_child;
+            sp += __popcll(mf);
+            const unsigned long long mn = __ballot(push_near);
+            if (push_near) w.stack[sp + __popcll(mn & ((1ull << lane) - 1ull))] = near_child;
+            sp += __popcll(mn);
+            if (count > kCap - 64) {                          // make room; tighten the radius
+                r2 = compress(w, count, k, lane);
+                evicted = true;
+            }
+        }
+        if (count > k) { r2 = compress(w, count, k, lane); evicted = true; }
+        const float r2_final = evicted ? r2 : md2;            // dist2[0] only moves once the heap overflows (:240)
+        float sr = 0.f, sg = 0.f, sb = 0.f;
+        for (int i = lane; i < count; i += 64) {
+            const float4 P = pm.power[w.idx[i]];
+            sr += P.x; sg += P.y; sb += P.z;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            sr += __shfl_xor(sr, off, 64); sg += __shfl_xor(sg, off, 64); sb += __shfl_xor(sb, off, 64);
+        }
+        if (lane == 0) {
+            const float tmp = (float)((1.0 / 3.14159265358979323846) / (double)r2_final);     // :136
+            irrad[3 * q] = sr * tmp; irrad[3 * q + 1] = sg * tmp; irrad[3 * q + 2] = sb * tmp;
+            if (found_out) found_out[q] = count;
+            if (r2_out) r2_out[q] = r2_final;
+        }
+    }
+}
+
+}  // namespace
+
+mr_status launch_irradiance(const PhotonMapDev &pm, const float *d_pos, const float *d_normal, unsigned long long nq,
+                            float max_dist, uint32_t k, float *d_irrad, int32_t *d_found, float *d_r2, hipStream_t stream) {
+    unsigned long long blocks = (nq + kWaves - 1) / kWaves;
+    if (blocks > 256ull * 16ull) blocks = 256ull * 16ull;
+    hipLaunchKernelGGL(irradiance_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, pm, d_pos, d_normal, nq, max_dist,
+                       (int)k, d_irrad, d_found, d_r2);
+    MR_HIP_CHECK(hipGetLastError());
+    return MR_OK;
+}
+
+}  // namespace mr

@@ -102,6 +102,29 @@ __global__ __launch_bounds__(kBlock) void shade_pixels_kernel(ShadeArgs a) {
     }
 }
 
+// one lane per sample (coalesced 16-byte hit / ray loads), then an xor-butterfly over the spp lanes of a pixel:
+// spp must be a power of two <= 64, so that a pixel's samples never straddle a wave.  The summation tree depends on
+// the sample index only, so the result is independent of how the frame is sharded.
+__global__ __launch_bounds__(kBlock) void shade_samples_kernel(ShadeArgs a, unsigned long long n_samples) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
+    const float inv_spp = 1.0f / (float)a.spp;
+    const unsigned long long n_round = (n_samples + 63ull) & ~63ull;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; k < n_round; k += stride) {
+        float c[3] = {0.f, 0.f, 0.f};
+        if (k < n_samples) shade_sample(a, k, c);
+        for (uint32_t off = 1; off < a.spp; off <<= 1) {
+            c[0] += __shfl_xor(c[0], (int)off, 64);
+            c[1] += __shfl_xor(c[1], (int)off, 64);
+            c[2] += __shfl_xor(c[2], (int)off, 64);
+        }
+        if (k < n_samples && (k & (a.spp - 1)) == 0) {
+            const unsigned long long pix = k / a.spp;
+            if (a.spp > 1) { c[0] *= inv_spp; c[1] *= inv_spp; c[2] *= inv_spp; }
+            a.rgb[3 * pix] = c[0]; a.rgb[3 * pix + 1] = c[1]; a.rgb[3 * pix + 2] = c[2];
+        }
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void tonemap_kernel(const float *rgb, unsigned long long n_values, uint8_t *out) {
     const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
     for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < n_values; i += stride) {
@@ -137,7 +160,10 @@ mr_status launch_shade(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit
     a.spp = spp;
     a.n_pixels = n / spp;
     a.rgb = d_rgb;
-    hipLaunchKernelGGL(shade_pixels_kernel, dim3(grid_for(a.n_pixels)), dim3(kBlock), 0, stream, a);
+    if (spp <= 64 && (spp & (spp - 1)) == 0)
+        hipLaunchKernelGGL(shade_samples_kernel, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, n);
+    else
+        hipLaunchKernelGGL(shade_pixels_kernel, dim3(grid_for(a.n_pixels)), dim3(kBlock), 0, stream, a);
     MR_HIP_CHECK(hipGetLastError());
     return MR_OK;
 }

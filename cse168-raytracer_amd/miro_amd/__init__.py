@@ -7,7 +7,7 @@ streams and torch.distributed only.  There is no CPU fallback anywhere in this p
 is missing it raises, and on a machine without a GPU every device call returns MR_ERR_HIP.
 """
 from .binding import (  # noqa: F401
-    HIT_DTYPE, RAY_DTYPE, MISS, MiroError, Scene, lib, lib_path, load_library,
+    HIT_DTYPE, RAY_DTYPE, MISS, MiroError, Scene, PhotonMap, lib, lib_path, load_library,
     MR_TRACE_CLOSEST, MR_TRACE_ANY, MR_RAYS_ON_DEVICE, MR_HITS_ON_DEVICE, MR_MATH_FAST, MR_COUNT_STATS, MR_TRACE_PERSISTENT,
     EXPORTED_SYMBOLS,
 )

@@ -29,6 +29,8 @@ EXPORTED_SYMBOLS = [
     "mr_bvh_build", "mr_scene_get_info", "mr_scene_get_mesh", "mr_scene_export_tree",
     "mr_trace", "mr_trace_indirect", "mr_trace_get_stats", "mr_gen_eye_rays", "mr_gen_shadow_rays", "mr_hit_attrs",
     "mr_shade_direct", "mr_tonemap",
+    "mr_photon_map_create", "mr_photon_map_destroy", "mr_photon_map_store", "mr_photon_map_scale",
+    "mr_photon_map_balance", "mr_photon_map_count", "mr_photon_map_export", "mr_irradiance_estimate",
     "mr_last_error", "mr_version",
 ]
 
@@ -107,6 +109,14 @@ def load_library(path=None):
     L.mr_hit_attrs.argtypes = [vp, vp, C.c_uint64, vp, vp, vp]
     L.mr_shade_direct.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, vp, C.POINTER(Light), f32p, C.c_uint32, vp, vp]
     L.mr_tonemap.argtypes = [vp, vp, C.c_uint64, vp, vp]
+    L.mr_photon_map_create.argtypes = [C.c_int32, C.c_uint32, C.POINTER(vp)]
+    L.mr_photon_map_destroy.argtypes = [vp]
+    L.mr_photon_map_store.argtypes = [vp, C.c_uint32, f32p, f32p, f32p]
+    L.mr_photon_map_scale.argtypes = [vp, C.c_float]
+    L.mr_photon_map_balance.argtypes = [vp, C.c_uint32]
+    L.mr_photon_map_count.argtypes = [vp, u32p]
+    L.mr_photon_map_export.argtypes = [vp, f32p, C.POINTER(C.c_int32), C.POINTER(C.c_uint8), f32p]
+    L.mr_irradiance_estimate.argtypes = [vp, vp, vp, C.c_uint64, C.c_float, C.c_uint32, vp, vp, vp, vp]
     for name in EXPORTED_SYMBOLS:
         if hasattr(L, name) and getattr(L, name).restype is C.c_int:
             getattr(L, name).restype = C.c_int32
@@ -279,3 +289,54 @@ class Scene:
 
     def tonemap(self, d_rgb, n_values, d_out, stream=None):
         _check(self.L.mr_tonemap(self.h, d_rgb.data_ptr(), n_values, d_out.data_ptr(), _stream_ptr(stream)))
+
+
+class PhotonMap:
+    """Photon_map (PhotonMap.h:42-105) on one device: store, scale_photon_power, balance, irradiance_estimate."""
+
+    def __init__(self, max_photons, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        _check(self.L.mr_photon_map_create(device, max_photons, C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mr_photon_map_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def store(self, power, pos, direction):
+        power, pos, direction = (np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 3) for x in (power, pos, direction))
+        _check(self.L.mr_photon_map_store(self.h, len(pos), _f32p(power), _f32p(pos), _f32p(direction)))
+
+    def scale_photon_power(self, scale):
+        _check(self.L.mr_photon_map_scale(self.h, scale))
+
+    def balance(self, host_only=False):
+        _check(self.L.mr_photon_map_balance(self.h, 1 if host_only else 0))
+
+    def count(self):
+        n = C.c_uint32(0)
+        _check(self.L.mr_photon_map_count(self.h, C.byref(n)))
+        return n.value
+
+    def export(self):
+        n = self.count()
+        pos, power = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32)
+        plane = np.empty(n, np.int32)
+        tp = np.empty((n, 2), np.uint8)
+        _check(self.L.mr_photon_map_export(self.h, _f32p(pos), plane.ctypes.data_as(C.POINTER(C.c_int32)),
+                                           tp.ctypes.data_as(C.POINTER(C.c_uint8)), _f32p(power)))
+        return pos, plane, tp, power
+
+    def irradiance_estimate(self, d_pos, d_normal, n, d_irrad, max_dist=1e10, nphotons=500, d_found=None, d_r2=None,
+                            stream=None):
+        """Device tensors: d_pos / d_normal [n,3] float32, d_irrad [n,3]; optional d_found int32 [n], d_r2 float32 [n]."""
+        _check(self.L.mr_irradiance_estimate(self.h, d_pos.data_ptr(), d_normal.data_ptr(), n, max_dist, nphotons,
+                                             d_irrad.data_ptr(), d_found.data_ptr() if d_found is not None else None,
+                                             d_r2.data_ptr() if d_r2 is not None else None, _stream_ptr(stream)))

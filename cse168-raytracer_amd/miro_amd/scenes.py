@@ -225,3 +225,30 @@ def write_obj(path, verts, faces):
         fh.write("# procedural atrium stand-in for sponza.obj (miro_amd.scenes.atrium_mesh, seed 168)\n")
         np.savetxt(fh, verts, fmt="v %.6f %.6f %.6f")
         np.savetxt(fh, faces, fmt="f %d %d %d")
+
+
+def synthetic_photons(v, vi, n, seed=168, power=1.0):
+    """Config 5's synthetic photon set: n photons uniform on the scene's surfaces (area-weighted),
+    incoming directions cosine-distributed about the inward side of the face normal, equal power.  Returns
+    (power[n,3], pos[n,3], dir[n,3]) float32.  Deterministic (numpy RandomState(seed))."""
+    rng = np.random.RandomState(seed)
+    v = np.asarray(v, np.float64)
+    vi = np.asarray(vi, np.int64)
+    a, b, c = v[vi[:, 0]], v[vi[:, 1]], v[vi[:, 2]]
+    fn = np.cross(b - a, c - a)
+    area = 0.5 * np.linalg.norm(fn, axis=1)
+    cdf = np.cumsum(area)
+    tri = np.searchsorted(cdf, rng.rand(n) * cdf[-1])
+    tri = np.minimum(tri, len(vi) - 1)
+    r1, r2 = np.sqrt(rng.rand(n)), rng.rand(n)
+    pos = (1 - r1)[:, None] * a[tri] + (r1 * (1 - r2))[:, None] * b[tri] + (r1 * r2)[:, None] * c[tri]
+    nrm = fn[tri] / np.maximum(np.linalg.norm(fn[tri], axis=1, keepdims=True), 1e-30)
+    # cosine-distributed direction about nrm, then reversed: the photon arrives against the normal
+    u1, u2 = rng.rand(n), rng.rand(n)
+    rr, phi = np.sqrt(u1), 2 * np.pi * u2
+    t1 = np.cross(nrm, np.where(np.abs(nrm[:, :1]) < 0.9, [[1.0, 0, 0]], [[0, 1.0, 0]]))
+    t1 /= np.linalg.norm(t1, axis=1, keepdims=True)
+    t2 = np.cross(nrm, t1)
+    d = rr[:, None] * np.cos(phi)[:, None] * t1 + rr[:, None] * np.sin(phi)[:, None] * t2 + np.sqrt(1 - u1)[:, None] * nrm
+    pw = np.full((n, 3), power, np.float32)
+    return pw, pos.astype(np.float32), (-d).astype(np.float32)

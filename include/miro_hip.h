@@ -161,6 +161,26 @@ mr_status mr_shade_direct(mr_scene *scene, const mr_ray *d_rays, const mr_hit *d
 /* sigmoid(6v-3) tone map + 8-bit quantisation (Scene.cpp:87-91,177-202; Image.cpp:44-50) */
 mr_status mr_tonemap(mr_scene *scene, const float *d_rgb, uint64_t n_values, uint8_t *d_out, void *stream);
 
+/* ---- photon map (BASELINE config 5): Photon_map of PhotonMap.h:42-105 ---------------------------------------- */
+typedef struct mr_photon_map mr_photon_map;
+mr_status mr_photon_map_create(int32_t device, uint32_t max_photons, mr_photon_map **out);     /* Photon_map(max_phot) */
+mr_status mr_photon_map_destroy(mr_photon_map *map);
+/* Photon_map::store (PhotonMap.cpp:255-289) for n photons: power, position, incoming direction (xyz triples);
+ * photons beyond max_photons are dropped silently, as in the reference */
+mr_status mr_photon_map_store(mr_photon_map *map, uint32_t n, const float *power, const float *pos, const float *dir);
+mr_status mr_photon_map_scale(mr_photon_map *map, float scale);        /* scale_photon_power (:298-306) */
+/* Photon_map::balance (:314-359): left-balanced kd-tree in heap order; uploads unless host_only */
+mr_status mr_photon_map_balance(mr_photon_map *map, uint32_t host_only);
+mr_status mr_photon_map_count(const mr_photon_map *map, uint32_t *stored);
+/* balanced tree in heap order (any pointer may be NULL): pos[3n], plane[n], theta_phi[2n] (quantised direction), power[3n] */
+mr_status mr_photon_map_export(const mr_photon_map *map, float *pos, int32_t *plane, uint8_t *theta_phi, float *power);
+/* Photon_map::irradiance_estimate (:81-145), batched: for each query (surface position + normal, xyz triples on the
+ * device) the nphotons (<= 512) nearest photons within max_dist whose incoming direction faces the normal;
+ * d_irrad[3q..] = sum of their powers * (1/pi)/r^2.  d_found / d_r2 (optional) receive np.found and np.dist2[0]. */
+mr_status mr_irradiance_estimate(mr_photon_map *map, const float *d_pos, const float *d_normal, uint64_t n_queries,
+                                 float max_dist, uint32_t nphotons, float *d_irrad, int32_t *d_found, float *d_r2,
+                                 void *stream);
+
 const char *mr_last_error(void);
 const char *mr_version(void);
 

@@ -103,6 +103,20 @@ void orc_shade_direct(const orc_scene *, const orc_ray *rays, const orc_hit *hit
                       float wattage, const float diffuse[3], int spp, float *rgb);
 void orc_tonemap(const float *rgb, uint64_t n_values, unsigned char *out);
 
+/* Photon map (miro_oracle_photon.c): Photon_map::store / scale_photon_power / balance / irradiance_estimate */
+typedef struct orc_pmap orc_pmap;
+orc_pmap *orc_pmap_new(int max_photons);
+void orc_pmap_free(orc_pmap *);
+int  orc_pmap_count(const orc_pmap *);
+void orc_pmap_store(orc_pmap *, int n, const float *power, const float *pos, const float *dir);
+void orc_pmap_scale(orc_pmap *, float scale);
+void orc_pmap_balance(orc_pmap *);
+void orc_pmap_irradiance(const orc_pmap *, uint64_t nq, const float *pos, const float *normal, float max_dist,
+                         int nphotons, float *irrad, int *found, float *r2);
+void orc_pmap_irradiance_brute(const orc_pmap *, uint64_t nq, const float *pos, const float *normal, float max_dist,
+                               int nphotons, float *irrad, int *found, float *r2);
+void orc_pmap_export(const orc_pmap *, float *pos, int *plane, unsigned char *theta_phi, float *power);
+
 uint32_t orc_hash(uint32_t x);
 
 #ifdef __cplusplus

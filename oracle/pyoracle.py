@@ -67,6 +67,16 @@ def lib():
         L.orc_hit_attrs.argtypes = [vp, vp, C.c_uint64, f32p, f32p]
         L.orc_shade_direct.argtypes = [vp, vp, vp, C.c_uint64, vp, f32p, f32p, C.c_float, f32p, C.c_int, f32p]
         L.orc_tonemap.argtypes = [f32p, C.c_uint64, vp]
+        L.orc_pmap_new.argtypes = [C.c_int]
+        L.orc_pmap_new.restype = vp
+        L.orc_pmap_free.argtypes = [vp]
+        L.orc_pmap_count.argtypes = [vp]
+        L.orc_pmap_store.argtypes = [vp, C.c_int, f32p, f32p, f32p]
+        L.orc_pmap_scale.argtypes = [vp, C.c_float]
+        L.orc_pmap_balance.argtypes = [vp]
+        L.orc_pmap_irradiance.argtypes = [vp, C.c_uint64, f32p, f32p, C.c_float, C.c_int, f32p, C.POINTER(C.c_int), f32p]
+        L.orc_pmap_irradiance_brute.argtypes = [vp, C.c_uint64, f32p, f32p, C.c_float, C.c_int, f32p, C.POINTER(C.c_int), f32p]
+        L.orc_pmap_export.argtypes = [vp, f32p, C.POINTER(C.c_int), C.POINTER(C.c_ubyte), f32p]
         L.orc_hash.argtypes = [C.c_uint32]
         L.orc_hash.restype = C.c_uint32
         _lib = L
@@ -210,6 +220,53 @@ class Scene:
         N = np.empty((len(hits), 3), np.float32)
         self.L.orc_hit_attrs(self.h, hits.ctypes.data, len(hits), _f32p(P), _f32p(N))
         return P, N
+
+
+class PhotonMap:
+    """Photon_map (PhotonMap.h:42-105): store, scale_photon_power, balance, irradiance_estimate."""
+
+    def __init__(self, max_photons):
+        self.L = lib()
+        self.h = self.L.orc_pmap_new(max_photons)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.orc_pmap_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def store(self, power, pos, direction):
+        power, pos, direction = (np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 3) for x in (power, pos, direction))
+        self.L.orc_pmap_store(self.h, len(pos), _f32p(power), _f32p(pos), _f32p(direction))
+
+    def scale_photon_power(self, scale):
+        self.L.orc_pmap_scale(self.h, scale)
+
+    def balance(self):
+        self.L.orc_pmap_balance(self.h)
+
+    def count(self):
+        return self.L.orc_pmap_count(self.h)
+
+    def irradiance_estimate(self, pos, normal, max_dist=1e10, nphotons=500, brute=False):
+        pos, normal = (np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 3) for x in (pos, normal))
+        n = len(pos)
+        irr = np.empty((n, 3), np.float32)
+        found = np.empty(n, np.int32)
+        r2 = np.empty(n, np.float32)
+        fn = self.L.orc_pmap_irradiance_brute if brute else self.L.orc_pmap_irradiance
+        fn(self.h, n, _f32p(pos), _f32p(normal), max_dist, nphotons, _f32p(irr), found.ctypes.data_as(C.POINTER(C.c_int)), _f32p(r2))
+        return irr, found, r2
+
+    def export(self):
+        n = self.count()
+        pos, power = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32)
+        plane = np.empty(n, np.int32)
+        tp = np.empty((n, 2), np.uint8)
+        self.L.orc_pmap_export(self.h, _f32p(pos), plane.ctypes.data_as(C.POINTER(C.c_int)), tp.ctypes.data_as(C.POINTER(C.c_ubyte)), _f32p(power))
+        return pos, plane, tp, power
 
 
 def tonemap(rgb):

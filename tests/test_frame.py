@@ -78,7 +78,7 @@ gpu = pytest.mark.gpu
 
 
 @gpu
-@pytest.mark.parametrize("name,spp", [("teapot", 1), ("bunny", 4), ("sponza", 2)])
+@pytest.mark.parametrize("name,spp", [("teapot", 1), ("bunny", 4), ("sponza", 2), ("teapot", 3), ("cornell", 64)])
 def test_frame_pipeline_matches_oracle(oracle, miro, name, spp):
     """gen -> trace -> shadow gen -> indirect trace -> shade on the device vs the restated
     raytraceImage / Phong::shade on the CPU: hits bit-exact, colours within 1e-5 (powf/rounding)."""
