@@ -27,12 +27,16 @@ constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr int kCap = 1024;         // candidate slots per wave
 constexpr int kStack = 512;        // pending block roots per wave
+constexpr int kTighten = 640;      // compress (tighten the radius) once this many candidates are buffered
 
 struct WaveLds {
     float d2[kCap];
     int idx[kCap];
     int stack[kStack];
+    float lb[kStack];        // per pending block: squared distance of the farthest plane crossed on the far side
     unsigned hist[256];
+    int slot[64];            // children of one block, indexed by visiting-order key
+    float slot_lb[64];
 };
 
 // k-th smallest (1-based rank `k`) of d2[0..count): returns its bit pattern and how many entries equal to it belong
@@ -128,11 +132,13 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
         int count = 0;
         bool evicted = false;
         int sp = 0;
-        if (pm.n >= 1) { if (lane == 0) w.stack[0] = 1; sp = 1; }
+        if (pm.n >= 1) { if (lane == 0) { w.stack[0] = 1; w.lb[0] = 0.0f; } sp = 1; }
 
         while (sp > 0) {
             sp--;
             const int b = w.stack[sp];                        // same address in every lane: LDS broadcast
+            const float lb_block = w.lb[sp];
+            if (lb_block >= r2) continue;                     // the plane that led here is no longer inside the radius
             const long long jj = ((long long)b << lv) + off_in_level;
             const bool valid = node_lane && jj <= (long long)pm.n;
             const int j = valid ? (int)jj : 0;
@@ -143,15 +149,25 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
             const float qc = plane == 0 ? qx : (plane == 1 ? qy : qz);
             const float d1 = qc - pc;                         // :161
             const bool desc = valid && j < pm.half;           // :160
-            // reachability inside the block, level by level
+            // reachability inside the block, level by level; `path` collects the far-side steps (most significant =
+            // nearest the block root), which is the order the reference's near-first recursion visits subtrees in;
+            // `lb` is the largest squared plane distance crossed on the far side (a lower bound of the distance)
             bool reach = valid && lv == 0;
+            int path = 0;
+            float lb = lb_block;
             for (int L = 1; L <= 5; L++) {
                 const int p_reach = __shfl((int)reach, parent_lane, 64);
                 const int p_desc = __shfl((int)desc, parent_lane, 64);
                 const float p_d1 = __shfl(d1, parent_lane, 64);
+                const int p_path = __shfl(path, parent_lane, 64);
+                const float p_lb = __shfl(lb, parent_lane, 64);
                 if (lv == L && valid) {
                     const bool is_right = (j & 1) != 0, near_right = p_d1 > 0.0f;     // :163-172
-                    reach = p_reach && p_desc && (is_right == near_right || p_d1 * p_d1 < r2);
+                    const bool far_step = is_right != near_right;
+                    const float pd2 = p_d1 * p_d1;
+                    reach = p_reach && p_desc && (!far_step || pd2 < r2);
+                    path = (p_path << 1) | (far_step ? 1 : 0);
+                    lb = far_step ? fmaxf(p_lb, pd2) : p_lb;
                 }
             }
             // the photon itself (:177-186)
@@ -167,19 +183,26 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
                 w.d2[pos] = d2; w.idx[pos] = j;
             }
             count += __popcll(mc);
-            // children of the level-5 nodes become block roots: far side first, near side last (popped first)
+            // children of the level-5 nodes become block roots, pushed so that they pop in the reference's order:
+            // key = far-step bits of the whole path (6 bits, unique per child); slot[key] is filled by its owner,
+            // then lane `key` moves it to the stack behind all larger keys
+            w.slot[lane] = 0;
             const bool can_push = valid && lv == 5 && reach && desc;
             const int near_child = d1 > 0.0f ? 2 * j + 1 : 2 * j;
             const int far_child = near_child ^ 1;
-            const bool push_far = can_push && far_child <= pm.n && d1 * d1 < r2;
-            const bool push_near = can_push && near_child <= pm.n;
-            const unsigned long long mf = __ballot(push_far);
-            if (push_far) w.stack[sp + __popcll(mf & ((1ull << lane) - 1ull))] = far_child;
-            sp += __popcll(mf);
-            const unsigned long long mn = __ballot(push_near);
-            if (push_near) w.stack[sp + __popcll(mn & ((1ull << lane) - 1ull))] = near_child;
-            sp += __popcll(mn);
-            if (count > kCap - 64) {                          // make room; tighten the radius
+            const float dsq = d1 * d1;
+            if (can_push && near_child <= pm.n) { w.slot[path << 1] = near_child; w.slot_lb[path << 1] = lb; }
+            if (can_push && far_child <= pm.n && dsq < r2) { w.slot[(path << 1) | 1] = far_child; w.slot_lb[(path << 1) | 1] = fmaxf(lb, dsq); }
+            const int child = w.slot[lane];
+            const float child_lb = w.slot_lb[lane];
+            const unsigned long long mp = __ballot(child != 0);
+            if (child != 0) {
+                const unsigned long long higher = lane == 63 ? 0ull : (mp >> (lane + 1));
+                const int pos = sp + __popcll(higher);
+                w.stack[pos] = child; w.lb[pos] = child_lb;
+            }
+            sp += __popcll(mp);
+            if (count > kTighten && count > k) {              // keep the k nearest so far; the k-th is the new radius
                 r2 = compress(w, count, k, lane);
                 evicted = true;
             }

@@ -1,0 +1,42 @@
+"""Timing of mr_irradiance_estimate (BASELINE config 5): 200 000 photons on the scene's surfaces, queries = the
+hit points + normals of a 1920x1080 1 spp frame, k = 500, max_dist = 1e10 (Miro.h:16-17).
+usage: python tools/photon_probe.py [--photons 200000] [--k 500]"""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "cse168-raytracer_amd"))
+import numpy as np, torch
+import miro_amd
+from miro_amd import frame as mframe, scenes
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scene", default="sponza")
+ap.add_argument("--photons", type=int, default=200000)
+ap.add_argument("--k", type=int, default=500)
+ap.add_argument("--w", type=int, default=1920)
+ap.add_argument("--h", type=int, default=1080)
+ap.add_argument("--reps", type=int, default=3)
+a = ap.parse_args()
+sc = miro_amd.Scene(0); scenes.populate(sc, a.scene); sc.build(4)
+v, _, vi, _ = sc.arrays()
+pw, pos, d = scenes.synthetic_photons(v, vi, a.photons)
+pm = miro_amd.PhotonMap(a.photons); pm.store(pw, pos, d); pm.scale_photon_power(1.0 / a.photons)
+t0 = time.time(); pm.balance(); print("balance+upload %.3f s for %d photons" % (time.time() - t0, pm.count()))
+fr = mframe.FrameRenderer(sc, a.scene, a.w, a.h, spp=1); fr.generate(); fr.trace_primary()
+n = fr.n
+P = torch.empty((n, 3), device="cuda"); N = torch.empty((n, 3), device="cuda")
+sc.hit_attrs(fr.d_hits, n, P, N)
+N = N / N.norm(dim=1, keepdim=True)
+hit = fr.d_hits.view(torch.int32)[:, 1] != -1
+P, N = P[hit].contiguous(), N[hit].contiguous()
+nq = P.shape[0]
+out = torch.empty((nq, 3), device="cuda"); fnd = torch.empty(nq, dtype=torch.int32, device="cuda")
+st = torch.cuda.current_stream()
+pm.irradiance_estimate(P, N, nq, out, nphotons=a.k, d_found=fnd, stream=st)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(st)
+for _ in range(a.reps):
+    pm.irradiance_estimate(P, N, nq, out, nphotons=a.k, stream=st)
+e1.record(st); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / a.reps
+print("%d queries, k=%d: %.2f ms  %.2f Mqueries/s  (found min %d max %d, mean irradiance %.4g)" %
+      (nq, a.k, ms, nq / ms / 1e3, int(fnd.min()), int(fnd.max()), float(out.mean())))
