@@ -9,6 +9,7 @@ set -o pipefail
 TAG=${1:-r01}; shift
 ARGS=${@:-"--steps 3 --warmup 1 --no-cpu-baseline"}
 OUT=gpurun_out/prof_${TAG}
+rm -rf "$OUT"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/trace.log" 2>&1 || { tail -5 "$OUT/trace.log"; exit 1; }

@@ -77,7 +77,7 @@ def main():
                                                "%.1f" % (sum(f) / len(f)) if f else "-", "%.1f" % (sum(w) / len(w)) if w else "-"))
 
     traffic = None
-    main_k = [k for k in kernels if k.startswith("trace_kernel<true, false, false>")]
+    main_k = [k for k in kernels if k.startswith("trace_kernel<true, false, false")]
     if bench_line and main_k and fetch.get(main_k[0]) and write.get(main_k[0]):
         k = main_k[0]
         cfg = bench_line["config"]
