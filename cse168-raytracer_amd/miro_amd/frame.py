@@ -39,6 +39,13 @@ def gather_framebuffer(local_rgb, H, W, band, rank, world, group=None, dst=0):
     send[:counts[rank] * W] = local_rgb.reshape(-1, 3)[:counts[rank] * W]
     if world == 1:
         recv = [send]
+    elif send.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal of the multi-rank path on a box with fewer GPUs than ranks (MIRO_DIST_BACKEND=gloo): gloo has no
+        # CUDA gather, so the shard is staged through the host; the production path is the RCCL branch below
+        send_h = send.cpu()
+        recv_h = [torch.empty_like(send_h) for _ in range(world)] if rank == dst else None
+        dist.gather(send_h, recv_h, dst=dst, group=group)
+        recv = [t.to(send.device) for t in recv_h] if rank == dst else None
     else:
         recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
         dist.gather(send, recv, dst=dst, group=group)
