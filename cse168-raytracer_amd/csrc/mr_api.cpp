@@ -45,12 +45,17 @@ void release_device(mr_scene *s) {
     (void)hipFree(s->d_occluded);
     s->d_occluded = nullptr;
     s->occluded_cap = 0;
+    (void)hipFree(s->d_light_scale);
+    s->d_light_scale = nullptr;
+    s->light_scale_cap = 0;
 }
 
 inline int32_t leaf_ref(uint32_t first, uint32_t count) {
     const uint32_t c = count < (uint32_t)kLeafCountMask ? count : (uint32_t)kLeafCountMask;
     return (int32_t)~((first << kLeafCountBits) | c);
 }
+
+mr_status upload_materials(mr_scene *s);
 
 // host tree -> device records
 mr_status flatten_and_upload(mr_scene *s) {
@@ -124,6 +129,23 @@ mr_status flatten_and_upload(mr_scene *s) {
     MR_HIP_CHECK(hipMemset(s->d_stats, 0, 2 * sizeof(unsigned long long)));
     MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&s->d_work_counters), kWorkCounters * sizeof(unsigned long long)));
     MR_HIP_CHECK(hipMemset(s->d_work_counters, 0, kWorkCounters * sizeof(unsigned long long)));
+    return upload_materials(s);
+}
+
+// default: one white Lambert = Phong(Vector3(1)) (Lambert.h:9, Phong.h:10-14: shininess 1, index 1)
+mr_status upload_materials(mr_scene *s) {
+    DeviceScene &d = s->dev;
+    (void)hipFree(d.materials); (void)hipFree(d.prim_material);
+    d.materials = nullptr; d.prim_material = nullptr;
+    static const float white[11] = {1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1};
+    const float *src = s->materials.empty() ? white : s->materials.data();
+    const size_t nfl = s->materials.empty() ? 11 : s->materials.size();
+    MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d.materials), nfl * sizeof(float)));
+    MR_HIP_CHECK(hipMemcpy(d.materials, src, nfl * sizeof(float), hipMemcpyHostToDevice));
+    if (!s->prim_material.empty()) {
+        MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d.prim_material), s->prim_material.size() * sizeof(uint32_t)));
+        MR_HIP_CHECK(hipMemcpy(d.prim_material, s->prim_material.data(), s->prim_material.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     return MR_OK;
 }
 
@@ -408,6 +430,70 @@ mr_status mr_shade_direct(mr_scene *s, const mr_ray *d_rays, const mr_hit *d_hit
     return launch_shade(s->dev, d_rays, d_hits, n, d_shadow_hits, d_shadow_src,
                         reinterpret_cast<const unsigned long long *>(d_shadow_count), s->d_occluded, *light, diffuse, spp,
                         d_rgb, static_cast<hipStream_t>(stream));
+}
+
+mr_status mr_scene_set_materials(mr_scene *s, const mr_material *mats, uint32_t n_mats, const uint32_t *prim_material) {
+    if (!s || !mats || n_mats == 0) return fail(MR_ERR_INVALID, "NULL argument or no materials");
+    const uint32_t nt = s->mesh.n_triangles();
+    if (prim_material)
+        for (uint32_t i = 0; i < nt; i++)
+            if (prim_material[i] >= n_mats) return fail(MR_ERR_INVALID, "triangle %u has material %u of %u", i, prim_material[i], n_mats);
+    s->materials.resize(11 * (size_t)n_mats);
+    for (uint32_t i = 0; i < n_mats; i++) {
+        float *o = &s->materials[11 * (size_t)i];
+        // energy balance of the Phong constructor (Phong.cpp:12-33)
+        for (int c = 0; c < 3; c++) {
+            const float ks = mats[i].specular[c];
+            const float kt = fmaxf(fminf(mats[i].transmission[c], 1.0f - ks), 0.f);
+            const float kd = fmaxf(fminf(mats[i].diffuse[c], 1.0f - ks - kt), 0.f);
+            o[c] = kd; o[3 + c] = ks; o[6 + c] = kt;
+        }
+        o[9] = mats[i].shininess;
+        o[10] = mats[i].refract_index;
+    }
+    if (prim_material) s->prim_material.assign(prim_material, prim_material + nt);
+    else s->prim_material.clear();
+    if (s->on_device) {
+        MR_HIP_CHECK(hipSetDevice(s->device));
+        MR_HIP_CHECK(hipDeviceSynchronize());
+        return upload_materials(s);
+    }
+    return MR_OK;
+}
+
+mr_status mr_shade_accumulate(mr_scene *s, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
+                              const uint32_t *d_pixels, uint64_t n, const mr_ray *d_shadow_rays, const mr_hit *d_shadow_hits,
+                              const uint32_t *d_shadow_src, const uint64_t *d_shadow_count, const mr_light *light, uint32_t spp,
+                              float *d_rgb, void *stream) {
+    mr_status st = require_device(s);
+    if (st != MR_OK) return st;
+    if (!d_rays || !d_hits || !d_shadow_rays || !d_shadow_hits || !d_shadow_src || !d_shadow_count || !light || !d_rgb)
+        return fail(MR_ERR_INVALID, "NULL argument");
+    if (spp == 0) return fail(MR_ERR_INVALID, "spp is 0");
+    MR_HIP_CHECK(hipSetDevice(s->device));
+    if (n > s->light_scale_cap) {
+        (void)hipFree(s->d_light_scale);
+        s->d_light_scale = nullptr;
+        s->light_scale_cap = 0;
+        MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&s->d_light_scale), n * sizeof(float)));
+        s->light_scale_cap = n;
+    }
+    return launch_shade_accumulate(s->dev, d_rays, d_hits, d_weights, d_pixels, n, d_shadow_rays, d_shadow_hits, d_shadow_src,
+                                   reinterpret_cast<const unsigned long long *>(d_shadow_count), s->d_light_scale, *light, spp,
+                                   d_rgb, static_cast<hipStream_t>(stream));
+}
+
+mr_status mr_gen_secondary_rays(mr_scene *s, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
+                                const uint32_t *d_pixels, uint64_t n, uint32_t spp, mr_ray *d_out_rays, float *d_out_weights,
+                                uint32_t *d_out_pixels, uint64_t *d_count, void *stream) {
+    mr_status st = require_device(s);
+    if (st != MR_OK) return st;
+    if (!d_rays || !d_hits || !d_out_rays || !d_out_weights || !d_out_pixels || !d_count) return fail(MR_ERR_INVALID, "NULL argument");
+    if (spp == 0) return fail(MR_ERR_INVALID, "spp is 0");
+    if (n / spp > 0xFFFFFFFFull) return fail(MR_ERR_INVALID, "too many pixels");
+    MR_HIP_CHECK(hipSetDevice(s->device));
+    return launch_secondary_rays(s->dev, d_rays, d_hits, d_weights, d_pixels, n, spp, d_out_rays, d_out_weights, d_out_pixels,
+                                 reinterpret_cast<unsigned long long *>(d_count), static_cast<hipStream_t>(stream));
 }
 
 mr_status mr_tonemap(mr_scene *s, const float *d_rgb, uint64_t n_values, uint8_t *d_out, void *stream) {

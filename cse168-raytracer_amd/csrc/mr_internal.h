@@ -77,6 +77,10 @@ struct DeviceScene {
     // original indexed mesh, for HitInfo reconstruction and shadow-ray origins
     float    *v = nullptr, *n = nullptr;
     uint32_t *vi = nullptr, *ni = nullptr;
+    // materials (11 floats each: diffuse, specular, transmission, shininess, refraction index) and the material of
+    // every triangle; prim_material == nullptr means material 0 everywhere
+    float    *materials = nullptr;
+    uint32_t *prim_material = nullptr;
     float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
     int32_t root_ref = 0;
     uint32_t n_inner = 0, n_tris = 0, stack_depth = 1;
@@ -114,6 +118,15 @@ mr_status launch_shade(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit
                        hipStream_t stream);
 mr_status launch_tonemap(const float *d_rgb, unsigned long long n_values, uint8_t *d_out, hipStream_t stream);
 
+mr_status launch_shade_accumulate(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
+                                  const uint32_t *d_pixels, unsigned long long n, const mr_ray *d_shadow_rays,
+                                  const mr_hit *d_shadow_hits, const uint32_t *d_shadow_src,
+                                  const unsigned long long *d_shadow_count, float *d_light_scale, const mr_light &light,
+                                  uint32_t spp, float *d_rgb, hipStream_t stream);
+mr_status launch_secondary_rays(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
+                                const uint32_t *d_pixels, unsigned long long n, uint32_t spp, mr_ray *d_out_rays,
+                                float *d_out_weights, uint32_t *d_out_pixels, unsigned long long *d_count, hipStream_t stream);
+
 // photon map on the device: three float4 planes in kd-tree heap order, 1-based (children of i: 2i, 2i+1)
 struct PhotonMapDev {
     float4 *posplane = nullptr;   // (x, y, z, split axis as int bits)
@@ -143,4 +156,10 @@ struct mr_scene {
     // grow-only per-primary-ray occlusion flags for mr_shade_direct
     uint8_t *d_occluded = nullptr;
     uint64_t occluded_cap = 0;
+    // grow-only per-ray light attenuation for mr_shade_accumulate
+    float *d_light_scale = nullptr;
+    uint64_t light_scale_cap = 0;
+    // materials (host copy; uploaded by mr_scene_set_materials / mr_bvh_build)
+    std::vector<float> materials;          // 11 per material, clamped as the Phong constructor does
+    std::vector<uint32_t> prim_material;   // empty: material 0 everywhere
 };

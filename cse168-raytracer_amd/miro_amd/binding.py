@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = [
     "mr_bvh_build", "mr_scene_get_info", "mr_scene_get_mesh", "mr_scene_export_tree",
     "mr_trace", "mr_trace_indirect", "mr_trace_get_stats", "mr_gen_eye_rays", "mr_gen_shadow_rays", "mr_hit_attrs",
     "mr_shade_direct", "mr_tonemap",
+    "mr_scene_set_materials", "mr_shade_accumulate", "mr_gen_secondary_rays",
     "mr_photon_map_create", "mr_photon_map_destroy", "mr_photon_map_store", "mr_photon_map_scale",
     "mr_photon_map_balance", "mr_photon_map_count", "mr_photon_map_export", "mr_irradiance_estimate",
     "mr_last_error", "mr_version",
@@ -67,6 +68,11 @@ class Camera(C.Structure):
 
 class Light(C.Structure):
     _fields_ = [("position", C.c_float * 3), ("color", C.c_float * 3), ("wattage", C.c_float)]
+
+
+class Material(C.Structure):
+    _fields_ = [("diffuse", C.c_float * 3), ("specular", C.c_float * 3), ("transmission", C.c_float * 3),
+                ("shininess", C.c_float), ("refract_index", C.c_float)]
 
 
 def lib_path():
@@ -119,6 +125,9 @@ def load_library(path=None):
     L.mr_hit_attrs.argtypes = [vp, vp, C.c_uint64, vp, vp, vp]
     L.mr_shade_direct.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, vp, C.POINTER(Light), f32p, C.c_uint32, vp, vp]
     L.mr_tonemap.argtypes = [vp, vp, C.c_uint64, vp, vp]
+    L.mr_scene_set_materials.argtypes = [vp, C.POINTER(Material), C.c_uint32, u32p]
+    L.mr_shade_accumulate.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, C.POINTER(Light), C.c_uint32, vp, vp]
+    L.mr_gen_secondary_rays.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp, vp]
     L.mr_photon_map_create.argtypes = [C.c_int32, C.c_uint32, C.POINTER(vp)]
     L.mr_photon_map_destroy.argtypes = [vp]
     L.mr_photon_map_store.argtypes = [vp, C.c_uint32, f32p, f32p, f32p]
@@ -296,6 +305,41 @@ class Scene:
         _check(self.L.mr_shade_direct(self.h, d_rays.data_ptr(), d_hits.data_ptr(), n, d_shadow_hits.data_ptr(),
                                       d_shadow_src.data_ptr(), d_shadow_count.data_ptr(), C.byref(lt), _f32p(df), spp,
                                       d_rgb.data_ptr(), _stream_ptr(stream)))
+
+    def set_materials(self, materials, prim_material=None):
+        """materials: list of (diffuse, specular, transmission, shininess, refract_index) as Phong's constructor takes
+        them (Phong.h:10-14); prim_material: material id per triangle (None: material 0 everywhere)."""
+        arr = (Material * len(materials))()
+        for i, (kd, ks, kt, sh, ri) in enumerate(materials):
+            arr[i].diffuse[:] = kd
+            arr[i].specular[:] = ks
+            arr[i].transmission[:] = kt
+            arr[i].shininess = sh
+            arr[i].refract_index = ri
+        pm = None
+        if prim_material is not None:
+            pm = np.ascontiguousarray(prim_material, dtype=np.uint32)
+        _check(self.L.mr_scene_set_materials(self.h, arr, len(materials), _u32p(pm) if pm is not None else None))
+
+    def shade_accumulate(self, d_rays, d_hits, d_weights, d_pixels, n, d_shadow_rays, d_shadow_hits, d_shadow_src,
+                         d_shadow_count, light_pos, wattage, d_rgb, spp=1, color=(1.0, 1.0, 1.0), stream=None):
+        lt = Light()
+        lt.position[:] = light_pos
+        lt.color[:] = color
+        lt.wattage = wattage
+        _check(self.L.mr_shade_accumulate(self.h, d_rays.data_ptr(), d_hits.data_ptr(),
+                                          d_weights.data_ptr() if d_weights is not None else None,
+                                          d_pixels.data_ptr() if d_pixels is not None else None, n,
+                                          d_shadow_rays.data_ptr(), d_shadow_hits.data_ptr(), d_shadow_src.data_ptr(),
+                                          d_shadow_count.data_ptr(), C.byref(lt), spp, d_rgb.data_ptr(), _stream_ptr(stream)))
+
+    def gen_secondary_rays(self, d_rays, d_hits, d_weights, d_pixels, n, d_out_rays, d_out_weights, d_out_pixels, d_count,
+                           spp=1, stream=None):
+        _check(self.L.mr_gen_secondary_rays(self.h, d_rays.data_ptr(), d_hits.data_ptr(),
+                                            d_weights.data_ptr() if d_weights is not None else None,
+                                            d_pixels.data_ptr() if d_pixels is not None else None, n, spp,
+                                            d_out_rays.data_ptr(), d_out_weights.data_ptr(), d_out_pixels.data_ptr(),
+                                            d_count.data_ptr(), _stream_ptr(stream)))
 
     def tonemap(self, d_rgb, n_values, d_out, stream=None):
         _check(self.L.mr_tonemap(self.h, d_rgb.data_ptr(), n_values, d_out.data_ptr(), _stream_ptr(stream)))

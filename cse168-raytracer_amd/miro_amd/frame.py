@@ -122,6 +122,42 @@ class FrameRenderer:
         self.trace_shadow(stream, any_hit)
         self.shade(stream)
 
+    def render_specular(self, depth=10, stream=None):
+        """Scene::traceScene with reflective / refractive materials (Scene.cpp:270-346) as wavefront bounces: every
+        level traces its queue, shades it (weight x Phong::shade added to the ray's pixel), and emits the reflect /
+        Fresnel / refract children of the next level by ballot compaction.  depth = TRACE_DEPTH (Miro.h:13): rays are
+        traced while depth >= 0, i.e. up to depth+1 levels.  Returns the number of rays traced per level."""
+        sc, L, W = self.scene, self.desc["light"], self.desc["wattage"]
+        self.d_rgb.zero_()
+        rays, weights, pixels, n = self.d_rays, None, None, self.n
+        per_level = []
+        f32 = dict(dtype=torch.float32, device=self.device)
+        for level in range(depth + 1):
+            if n == 0:
+                break
+            hits = torch.empty((n, 4), **f32)
+            sh_rays = torch.empty((n, 8), **f32)
+            sh_hits = torch.empty((n, 4), **f32)
+            src = torch.empty(n, dtype=torch.int32, device=self.device)
+            cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
+            sc.trace_device(rays, n, hits, self.flags, stream=stream)
+            sc.gen_shadow_rays(rays, hits, n, L, sh_rays, src, cnt, stream=stream)
+            sc.trace_indirect(sh_rays, cnt, n, sh_hits, self.flags, stream=stream)       # closest hit: the occluder matters
+            sc.shade_accumulate(rays, hits, weights, pixels, n, sh_rays, sh_hits, src, cnt, L, W, self.d_rgb,
+                                spp=self.spp, stream=stream)
+            n_shadow = int(cnt.item())
+            per_level.append((n, n_shadow))
+            if level == depth:
+                break
+            out_rays = torch.empty((3 * n, 8), **f32)
+            out_w = torch.empty((3 * n, 3), **f32)
+            out_pix = torch.empty(3 * n, dtype=torch.int32, device=self.device)
+            cnt2 = torch.zeros(1, dtype=torch.int64, device=self.device)
+            sc.gen_secondary_rays(rays, hits, weights, pixels, n, out_rays, out_w, out_pix, cnt2, spp=self.spp, stream=stream)
+            n = int(cnt2.item())
+            rays, weights, pixels = out_rays[:n], out_w[:n], out_pix[:n]
+        return per_level
+
     def ray_counts(self):
         """(primary, shadow) of the last step -- synchronises."""
         return self.n, int(self.d_count.item()) if self.n else 0

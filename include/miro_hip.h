@@ -158,6 +158,30 @@ typedef struct mr_light {                             /* PointLight.h:8-59 */
 mr_status mr_shade_direct(mr_scene *scene, const mr_ray *d_rays, const mr_hit *d_hits, uint64_t n,
                           const mr_hit *d_shadow_hits, const uint32_t *d_shadow_src, const uint64_t *d_shadow_count,
                           const mr_light *light, const float diffuse[3], uint32_t spp, float *d_rgb, void *stream);
+/* ---- specular materials and secondary rays ("next" row: Scene::traceScene's recursion, Scene.cpp:302-336) -------- */
+typedef struct mr_material {                          /* Phong(kd, ks, kt, shininess, refractIndex), Phong.h:10-14 */
+    float diffuse[3], specular[3], transmission[3], shininess, refract_index;
+} mr_material;
+/* Materials of the scene (the Phong constructor's energy clamps are applied, Phong.cpp:12-33) and the material id
+ * of every triangle in addObject order (NULL: material 0 everywhere).  Without this call every triangle is the white
+ * Lambert of the BASELINE scenes.  May be called before or after mr_bvh_build. */
+mr_status mr_scene_set_materials(mr_scene *scene, const mr_material *materials, uint32_t n_materials,
+                                 const uint32_t *prim_material);
+/* Phong::shade with per-triangle materials for a batch of rays of any bounce: d_weights (rgb per ray, NULL = 1) is the
+ * product of reflection / transmission factors along the path, d_pixels (NULL = ray index / spp) the pixel the ray
+ * contributes to; light through refractive occluders is attenuated as Phong.cpp:99-113 does (needs the shadow rays
+ * themselves besides their hits).  Adds weight * L / spp to d_rgb[pixel] with float atomics. */
+mr_status mr_shade_accumulate(mr_scene *scene, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
+                              const uint32_t *d_pixels, uint64_t n, const mr_ray *d_shadow_rays, const mr_hit *d_shadow_hits,
+                              const uint32_t *d_shadow_src, const uint64_t *d_shadow_count, const mr_light *light, uint32_t spp,
+                              float *d_rgb, void *stream);
+/* Ray::reflect / getReflectionCoefficient / refract (Ray.h:143-243) for every hit on a reflective or refractive
+ * material: up to three children per ray (room for 3n), compacted by wave64 ballot + prefix sum, each with its path
+ * weight and pixel.  d_count: device uint64 receiving the number of children (zeroed by the call). */
+mr_status mr_gen_secondary_rays(mr_scene *scene, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
+                                const uint32_t *d_pixels, uint64_t n, uint32_t spp, mr_ray *d_out_rays, float *d_out_weights,
+                                uint32_t *d_out_pixels, uint64_t *d_count, void *stream);
+
 /* sigmoid(6v-3) tone map + 8-bit quantisation (Scene.cpp:87-91,177-202; Image.cpp:44-50) */
 mr_status mr_tonemap(mr_scene *scene, const float *d_rgb, uint64_t n_values, uint8_t *d_out, void *stream);
 

@@ -102,6 +102,11 @@ void orc_shade_direct(const orc_scene *, const orc_ray *rays, const orc_hit *hit
                       const unsigned char *occluded, const float light[3], const float color[3],
                       float wattage, const float diffuse[3], int spp, float *rgb);
 void orc_tonemap(const float *rgb, uint64_t n_values, unsigned char *out);
+/* Scene::traceScene (Scene.cpp:270-346) per ray for reflective / refractive Phong materials (11 floats each:
+ * diffuse, specular, transmission, shininess, refraction index, already clamped as Phong.cpp:12-33); returns the
+ * number of Scene::trace calls.  (miro_oracle_shade.c) */
+uint64_t orc_trace_scene(const orc_scene *, const float *materials, const uint32_t *prim_mat, const orc_ray *rays,
+                         uint64_t n, const float light[3], const float color[3], float wattage, int depth, float *rgb);
 
 /* Photon map (miro_oracle_photon.c): Photon_map::store / scale_photon_power / balance / irradiance_estimate */
 typedef struct orc_pmap orc_pmap;

@@ -67,6 +67,8 @@ def lib():
         L.orc_hit_attrs.argtypes = [vp, vp, C.c_uint64, f32p, f32p]
         L.orc_shade_direct.argtypes = [vp, vp, vp, C.c_uint64, vp, f32p, f32p, C.c_float, f32p, C.c_int, f32p]
         L.orc_tonemap.argtypes = [f32p, C.c_uint64, vp]
+        L.orc_trace_scene.argtypes = [vp, f32p, u32p, vp, C.c_uint64, f32p, f32p, C.c_float, C.c_int, f32p]
+        L.orc_trace_scene.restype = C.c_uint64
         L.orc_pmap_new.argtypes = [C.c_int]
         L.orc_pmap_new.restype = vp
         L.orc_pmap_free.argtypes = [vp]
@@ -213,6 +215,17 @@ class Scene:
         self.L.orc_shade_direct(self.h, rays.ctypes.data, hits.ctypes.data, len(rays), occ.ctypes.data,
                                 _f32p(l), _f32p(c), wattage, _f32p(d), spp, _f32p(rgb))
         return rgb
+
+    def trace_scene(self, materials, prim_mat, rays, light, wattage, depth=10, color=(1, 1, 1)):
+        """Scene::traceScene per ray; materials [n,11] already clamped; returns (rgb [n,3], Scene::trace calls)."""
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        m = np.ascontiguousarray(materials, dtype=np.float32).reshape(-1, 11)
+        pm = np.ascontiguousarray(prim_mat, dtype=np.uint32)
+        rgb = np.empty((len(rays), 3), np.float32)
+        l, c = (np.ascontiguousarray(x, dtype=np.float32) for x in (light, color))
+        calls = self.L.orc_trace_scene(self.h, _f32p(m), _u32p(pm), rays.ctypes.data, len(rays), _f32p(l), _f32p(c),
+                                       wattage, depth, _f32p(rgb))
+        return rgb, calls
 
     def hit_attrs(self, hits):
         hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
