@@ -232,6 +232,9 @@ def main():
                 "parallelism": "image rows in interleaved bands of %d over %d GPU(s), scene replicated, 1 RCCL gather of the framebuffer" % (a.band, world),
                 "resident_bytes_per_gpu": int(fr.bytes_resident() + info.device_bytes),
                 "bvh_build_s": round(t_build, 3),
+                # context only (other scene size, unstated CPU): the reference's write-up, sponza 512x512 1 spp with
+                # shadows, 524 288 rays in 0.166750 s (writeup/A2/Readme.tex:83,98) -- not this workload, so no vs_baseline
+                "reference_writeup_mrays_s_sponza_512x512": 3.14,
             },
             "roofline": {
                 "bound": "hbm",

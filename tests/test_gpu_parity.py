@@ -318,25 +318,27 @@ def test_shadow_ray_generator_and_hit_attrs(oracle, miro, torch_cuda, name):
 
 
 # ----------------------------------------------------------------------------------------------- full-size properties
-def test_full_size_properties(oracle, miro, torch_cuda):
-    """BASELINE-size batch (1920x1080, 4 spp of config 4) through size-independent properties:
+@pytest.mark.parametrize("name,W,H,spp,closed", [("sponza", 1920, 1080, 4, True), ("bunny", 1024, 1024, 16, False)])
+def test_full_size_properties(oracle, miro, torch_cuda, name, W, H, spp, closed):
+    """BASELINE-size batches (config 4: 1920x1080 at 4 of its 64 spp; config 3: bunny 1024x1024 16 spp in full)
+    through size-independent properties:
     (1) any prefix / permutation of the batch gives the same per-ray hits (rays are independent);
-    (2) re-tracing with tMax = t hits the same primitive at the same t (idempotence);
+    (2) re-tracing with tMax one ulp above t hits the same primitive at the same t (idempotence), except where the
+        reference itself does not (checked against the oracle);
     (3) shortening tMax below t turns every hit into a miss or a nearer-than-before impossibility;
     (4) a sub-sample agrees bit-for-bit with the oracle."""
     torch = torch_cuda
-    a, b = both(oracle, miro, "sponza")
+    a, b = both(oracle, miro, name)
     from miro_amd import binding
-    W, H, spp = 1920, 1080, 4
     n = W * H * spp
     d_rays = torch.empty((n, 8), dtype=torch.float32, device="cuda")
     d_hits = torch.empty((n, 4), dtype=torch.float32, device="cuda")
-    b.gen_eye_rays(camera_of(binding, "sponza"), W, H, d_rays, spp=spp, jitter=True, seed=168)
+    b.gen_eye_rays(camera_of(binding, name), W, H, d_rays, spp=spp, jitter=True, seed=168)
     b.trace_device(d_rays, n, d_hits)
     torch.cuda.synchronize()
     hits_bits = d_hits.view(torch.int32)
-    # closed scene: every primary ray hits
-    assert int((hits_bits[:, 1] == -1).sum()) == 0
+    n_miss = int((hits_bits[:, 1] == -1).sum())
+    assert (n_miss == 0) if closed else (0 < n_miss < n // 2)      # the atrium is closed; the bunny sits on a floor
     # (1) permutation
     perm = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
     d_hits2 = torch.empty_like(d_hits)
@@ -345,10 +347,21 @@ def test_full_size_properties(oracle, miro, torch_cuda):
     assert torch.equal(d_hits2.view(torch.int32), hits_bits[perm])
     # (2) idempotence with tMax one ulp above t (t == tMax itself loses the strict-less test, BVH.cpp:500)
     r2 = d_rays.clone()
-    r2[:, 7] = torch.nextafter(d_hits[:, 0], torch.full_like(d_hits[:, 0], float("inf")))
+    was_hit = hits_bits[:, 1] != -1
+    r2[:, 7] = torch.where(was_hit, torch.nextafter(d_hits[:, 0], torch.full_like(d_hits[:, 0], float("inf"))), d_rays[:, 7])
     b.trace_device(r2, n, d_hits2)
     torch.cuda.synchronize()
-    assert torch.equal(d_hits2.view(torch.int32), hits_bits)
+    # The reference's boxes are not conservative for every triangle (a leaf's hit point can lie outside an ancestor's
+    # padded box, so a subtree that a huge tMax lets the ray enter is culled by `minOverlap > tMax`, BVH.cpp:609, once
+    # tMax is near t): 3 of the bunny's 16.7 M rays turn into misses.  That is reference behaviour -- the rows that
+    # change must be few, must be misses, and must be exactly what the oracle returns for the shortened ray.
+    changed = (d_hits2.view(torch.int32) != hits_bits).any(dim=1).nonzero()[:, 0]
+    assert len(changed) <= max(1, n // 1_000_000)
+    if len(changed):
+        assert bool((d_hits2.view(torch.int32)[changed, 1] == -1).all())
+        sub = r2[changed].cpu().numpy().view(oracle.RAY_DTYPE).reshape(-1)
+        assert_hits_bit_exact(d_hits2[changed].cpu().numpy().view(miro.HIT_DTYPE).reshape(-1),
+                              a.trace(sub).view(miro.HIT_DTYPE))
     # (3) tMax = t: no hit can be the old one
     r2[:, 7] = d_hits[:, 0]
     b.trace_device(r2, n, d_hits2)
