@@ -96,6 +96,31 @@ __device__ __forceinline__ float vmin3(float a, float b, float c) {
     return o;
 }
 
+// two-input min/max as single VALU ops (no canonicalising v_max x,x in front, no NaN quieting: callers guarantee
+// NaN-free operands or want exactly the hardware's minNum/maxNum behaviour)
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float o;
+    asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+}
+__device__ __forceinline__ float vmin2(float a, float b) {
+    float o;
+    asm("v_min_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+}
+
+// min/max slab test of one child box for NaN-free rays on the reference's own products (corner - o) * (1/d):
+// 6 sub + 6 mul + 3 min + 3 max + max3 + min3.  Same entry/exit values as the select chain of slab_axis (up to
+// the sign of a zero, which no comparison sees).
+__device__ __forceinline__ void slab_box_minmax(float lox, float hix, float loy, float hiy, float loz, float hiz,
+                                                const RayRegs &r, float &mn, float &mx) {
+    const float ax = (lox - r.ox) * r.ix, bx = (hix - r.ox) * r.ix;
+    const float ay = (loy - r.oy) * r.iy, by = (hiy - r.oy) * r.iy;
+    const float az = (loz - r.oz) * r.iz, bz = (hiz - r.oz) * r.iz;
+    mn = vmax3(vmin2(ax, bx), vmin2(ay, by), vmin2(az, bz));
+    mx = vmin3(vmax2(ax, bx), vmax2(ay, by), vmax2(az, bz));
+}
+
 // Lean slab test of one child box for NaN-free rays: 6 fma + 3 min + 3 max + max3 + min3.  Entry/exit
 // distances differ from (corner - o) * (1/d) by rounding only; the decisions taken from them (cull, order) are
 // protected by the epsilon padding of every box (BVH.cpp:75-79) -- see DESIGN.md section 5.
@@ -152,12 +177,30 @@ __device__ __forceinline__ bool tri_test(const float4 q0, const float4 q1, const
 //            wave does the leaves together -- same per-lane visiting order, better SIMD utilisation in the
 //            triangle loop.
 // ---------------------------------------------------------------------------------------------------
+// `cur` is the node the lane is at: >= 0 inner node, < 0 leaf reference, kDone = no more work.  `sp` is the BYTE
+// offset in LDS of the lane's next free stack slot (slots of one lane are kBlock * 4 bytes apart); the bottom slot
+// of every lane holds kDone, so a pop needs no emptiness test: popping the sentinel ends the ray.
+constexpr int kDone = (int)0x80000000;
+constexpr int kStackStride = kBlock * (int)sizeof(int);
 struct Lane {
     float best_t, best_b, best_g;
     int best_pos;
     int sp, cur;
-    bool have;
+    __device__ __forceinline__ bool have() const { return cur != kDone; }
 };
+
+__device__ __forceinline__ void stack_push(Lane &L, int *s_stack, int v) {
+    *reinterpret_cast<int *>(reinterpret_cast<char *>(s_stack) + L.sp) = v;
+    L.sp += kStackStride;
+}
+__device__ __forceinline__ int stack_pop(Lane &L, int *s_stack) {
+    L.sp -= kStackStride;
+    return *reinterpret_cast<int *>(reinterpret_cast<char *>(s_stack) + L.sp);
+}
+__device__ __forceinline__ void stack_reset(Lane &L, int *s_stack, int tid) {
+    L.sp = tid * (int)sizeof(int);
+    stack_push(L, s_stack, kDone);
+}
 
 // One 64-byte node record through the scalar data cache: when every active lane of the wave sits at the same
 // node (coherent camera / shadow rays near the top of the tree), one s_load_dwordx16 replaces 64 lanes x 4
@@ -175,28 +218,31 @@ __device__ __forceinline__ void node_slabs(const float4 q0, const float4 q1, con
                                            float &mn0, float &mx0, float &mn1, float &mx1);
 
 // the post-test bookkeeping of BVH.cpp:609-651: near child first (ties -> child 0), far child pushed, else pop
-template <bool STATS>
+template <bool STATS, bool SAFE>
 __device__ __forceinline__ void node_decide(float mn0, float mx0, float mn1, float mx1, int ref0, int ref1,
-                                            const RayRegs &r, Lane &L, int *s_stack, int tid, Stats &st) {
+                                            const RayRegs &r, Lane &L, int *s_stack, Stats &st) {
     // tMax of this call == best_t: nothing changed since the node was entered
-    const bool h0 = !((mn0 > mx0) || (mn0 > L.best_t) || (mx0 < r.tmin));
-    const bool h1 = !((mn1 > mx1) || (mn1 > L.best_t) || (mx1 < r.tmin));
+    bool h0, h1;
+    if (SAFE) {
+        // mn, mx are not NaN here; (mn > mx || mn > best) == (mn > minNum(mx, best)) also when best is NaN
+        h0 = !((mn0 > vmin2(mx0, L.best_t)) || (mx0 < r.tmin));
+        h1 = !((mn1 > vmin2(mx1, L.best_t)) || (mx1 < r.tmin));
+    } else {
+        h0 = !((mn0 > mx0) || (mn0 > L.best_t) || (mx0 < r.tmin));
+        h1 = !((mn1 > mx1) || (mn1 > L.best_t) || (mx1 < r.tmin));
+    }
     const bool one_first = h1 && (!h0 || (mn0 > mn1));
     // (a select-only formulation with predicated push/pop was measured 5 % slower than this branch nest)
     if (h0 && h1) {
-        s_stack[L.sp * kBlock + tid] = one_first ? ref0 : ref1;
-        L.sp++;
+        stack_push(L, s_stack, one_first ? ref0 : ref1);
         L.cur = one_first ? ref1 : ref0;
         if (STATS) st.box++;
     } else if (h0 || h1) {
         L.cur = h0 ? ref0 : ref1;
         if (STATS) st.box++;
-    } else if (L.sp > 0) {
-        L.sp--;
-        L.cur = s_stack[L.sp * kBlock + tid];
-        if (STATS) st.box++;                  // the far child is entered unconditionally (:640-650)
     } else {
-        L.have = false;
+        L.cur = stack_pop(L, s_stack);        // the far child is entered unconditionally (:640-650); kDone at the bottom
+        if (STATS && L.cur != kDone) st.box++;
     }
 }
 
@@ -211,7 +257,7 @@ __device__ __forceinline__ void node_step(const TraceParams &p, const RayRegs &r
             const v16f v = load_node_scalar(p.nodes, cur0);
             node_slabs<EXACT, STATS, SLAB>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]),
                                            make_float4(v[8], v[9], v[10], v[11]), r, mn0, mx0, mn1, mx1);
-            node_decide<STATS>(mn0, mx0, mn1, mx1, __float_as_int(v[12]), __float_as_int(v[13]), r, L, s_stack, tid, st);
+            node_decide<STATS, SLAB != 0>(mn0, mx0, mn1, mx1, __float_as_int(v[12]), __float_as_int(v[13]), r, L, s_stack, st);
             return;
         }
     }
@@ -220,17 +266,17 @@ __device__ __forceinline__ void node_step(const TraceParams &p, const RayRegs &r
     const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2];
     const int4 q3 = *reinterpret_cast<const int4 *>(nd + 3);
     node_slabs<EXACT, STATS, SLAB>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
-    node_decide<STATS>(mn0, mx0, mn1, mx1, q3.x, q3.y, r, L, s_stack, tid, st);
+    node_decide<STATS, SLAB != 0>(mn0, mx0, mn1, mx1, q3.x, q3.y, r, L, s_stack, st);
 }
 
 template <bool EXACT, bool STATS, int SLAB>
 __device__ __forceinline__ void node_slabs(const float4 q0, const float4 q1, const float4 q2, const RayRegs &r,
                                            float &mn0, float &mx0, float &mn1, float &mx1) {
-    mn0 = -kInf; mx0 = kInf; mn1 = -kInf; mx1 = kInf;
     if (SLAB == 2) {
         slab_box_lean(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, r, mn0, mx0);
         slab_box_lean(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, r, mn1, mx1);
     } else if (EXACT && SLAB == 0) {
+        mn0 = -kInf; mx0 = kInf; mn1 = -kInf; mx1 = kInf;
         slab_axis<STATS>(q0.x, q0.y, r.ox, r.dx, r.ix, mn0, mx0);
         slab_axis<STATS>(q0.z, q0.w, r.oy, r.dy, r.iy, mn0, mx0);
         slab_axis<STATS>(q2.x, q2.y, r.oz, r.dz, r.iz, mn0, mx0);
@@ -238,12 +284,8 @@ __device__ __forceinline__ void node_slabs(const float4 q0, const float4 q1, con
         slab_axis<STATS>(q1.z, q1.w, r.oy, r.dy, r.iy, mn1, mx1);
         slab_axis<STATS>(q2.z, q2.w, r.oz, r.dz, r.iz, mn1, mx1);
     } else {
-        slab_axis_fast(q0.x, q0.y, r.ox, r.ix, mn0, mx0);
-        slab_axis_fast(q0.z, q0.w, r.oy, r.iy, mn0, mx0);
-        slab_axis_fast(q2.x, q2.y, r.oz, r.iz, mn0, mx0);
-        slab_axis_fast(q1.x, q1.y, r.ox, r.ix, mn1, mx1);
-        slab_axis_fast(q1.z, q1.w, r.oy, r.iy, mn1, mx1);
-        slab_axis_fast(q2.z, q2.w, r.oz, r.iz, mn1, mx1);
+        slab_box_minmax(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, r, mn0, mx0);
+        slab_box_minmax(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, r, mn1, mx1);
     }
 }
 
@@ -301,25 +343,22 @@ __device__ __forceinline__ void leaf_step(const TraceParams &p, const RayRegs &r
     }
     if (STATS) st.tri += cnt;
     if (ANY && done) {
-        L.have = false;
-    } else if (L.sp > 0) {
-        L.sp--;
-        L.cur = s_stack[L.sp * kBlock + tid];
-        if (STATS) st.box++;
+        L.cur = kDone;
     } else {
-        L.have = false;
+        L.cur = stack_pop(L, s_stack);
+        if (STATS && L.cur != kDone) st.box++;
     }
 }
 
 template <bool EXACT, bool ANY, bool STATS, int SLAB, bool WW, bool SCALAR>
 __device__ __forceinline__ void traverse(const TraceParams &p, const RayRegs &r, Lane &L, int *s_stack, int tid, Stats &st) {
     if (WW) {
-        while (__any(L.have)) {
-            while (L.have && L.cur >= 0) node_step<EXACT, STATS, SLAB, SCALAR>(p, r, L, s_stack, tid, st);
-            if (L.have) leaf_step<EXACT, ANY, STATS, SCALAR>(p, r, L, s_stack, tid, st);
+        while (__any(L.have())) {
+            while (L.cur >= 0) node_step<EXACT, STATS, SLAB, SCALAR>(p, r, L, s_stack, tid, st);
+            if (L.have()) leaf_step<EXACT, ANY, STATS, SCALAR>(p, r, L, s_stack, tid, st);
         }
     } else {
-        while (L.have) {
+        while (L.have()) {
             if (L.cur >= 0) node_step<EXACT, STATS, SLAB, SCALAR>(p, r, L, s_stack, tid, st);
             else leaf_step<EXACT, ANY, STATS, false>(p, r, L, s_stack, tid, st);
         }
@@ -358,15 +397,14 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(TraceParams p) {
         L.best_t = tmax0;                             // minHit.t = tMax (BVH.cpp:444)
         L.best_b = 0.0f; L.best_g = 0.0f;
         L.best_pos = -1;                              // leaf-order position of the winning triangle
-        L.sp = 0;                                     // entries of this lane on the LDS stack
+        stack_reset(L, s_stack, tid);                 // this lane's LDS stack: the kDone sentinel only
         {   // BVH::intersect root test (BVH.cpp:447-466)
             float mn = -kInf, mx = kInf;
             slab_axis<STATS>(p.root_lo[0], p.root_hi[0], r.ox, r.dx, r.ix, mn, mx);
             slab_axis<STATS>(p.root_lo[1], p.root_hi[1], r.oy, r.dy, r.iy, mn, mx);
             slab_axis<STATS>(p.root_lo[2], p.root_hi[2], r.oz, r.dz, r.iz, mn, mx);
             if (STATS && live) st.box++;
-            L.have = live && !((mn > mx) || (mn > tmax0) || (mx < r.tmin));
-            L.cur = p.root_ref;
+            L.cur = (live && !((mn > mx) || (mn > tmax0) || (mx < r.tmin))) ? p.root_ref : kDone;
         }
 
         if (kMinMax) {
@@ -429,14 +467,14 @@ __global__ __launch_bounds__(kBlock) void trace_persistent_kernel(TraceParams p,
     bool safe_lane = true;
     RayRegs r = {};
     Lane L;
-    L.best_t = 0.f; L.best_b = 0.f; L.best_g = 0.f; L.best_pos = -1; L.sp = 0; L.cur = 0; L.have = false;
+    L.best_t = 0.f; L.best_b = 0.f; L.best_g = 0.f; L.best_pos = -1; L.sp = 0; L.cur = kDone;
 
     while (true) {
-        const unsigned long long idle = __ballot(!L.have);
+        const unsigned long long idle = __ballot(!L.have());
         const int n_idle = __popcll(idle);
         if (n_idle >= REFILL_MIN || idle == ~0ull) {
             // retire the rays of the idle lanes
-            if (!L.have && my_idx != kNone) {
+            if (!L.have() && my_idx != kNone) {
                 mr_hit h;
                 if (L.best_pos >= 0) { h.t = L.best_t; h.prim = p.tri_prim[L.best_pos]; h.beta = L.best_b; h.gamma = L.best_g; }
                 else { h.t = tmax0; h.prim = MR_MISS; h.beta = 0.0f; h.gamma = 0.0f; }
@@ -452,26 +490,26 @@ __global__ __launch_bounds__(kBlock) void trace_persistent_kernel(TraceParams p,
             }
             if (pool_next < pool_end) {
                 const unsigned long long cand = pool_next + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
-                if (!L.have && cand < pool_end) {
+                if (!L.have() && cand < pool_end) {
                     my_idx = cand;
                     const float4 ra = reinterpret_cast<const float4 *>(p.rays)[2 * cand];
                     const float4 rb = reinterpret_cast<const float4 *>(p.rays)[2 * cand + 1];
                     ray_setup(r, ra, rb);
                     tmax0 = rb.w;
-                    L.best_t = tmax0; L.best_b = 0.0f; L.best_g = 0.0f; L.best_pos = -1; L.sp = 0;
+                    L.best_t = tmax0; L.best_b = 0.0f; L.best_g = 0.0f; L.best_pos = -1;
+                    stack_reset(L, s_stack, tid);
                     float mn = -kInf, mx = kInf;
                     slab_axis<false>(p.root_lo[0], p.root_hi[0], r.ox, r.dx, r.ix, mn, mx);
                     slab_axis<false>(p.root_lo[1], p.root_hi[1], r.oy, r.dy, r.iy, mn, mx);
                     slab_axis<false>(p.root_lo[2], p.root_hi[2], r.oz, r.dz, r.iz, mn, mx);
-                    L.have = !((mn > mx) || (mn > tmax0) || (mx < r.tmin));
-                    L.cur = p.root_ref;
+                    L.cur = !((mn > mx) || (mn > tmax0) || (mx < r.tmin)) ? p.root_ref : kDone;
                     safe_lane = lane_is_nan_free(r);
                 }
                 const unsigned long long adv = pool_next + (unsigned)n_idle;
                 pool_next = adv < pool_end ? adv : pool_end;
             }
         }
-        if (!__any(L.have)) {
+        if (!__any(L.have())) {
             if (exhausted && pool_next == pool_end) {
                 if (my_idx != kNone) {              // rays that missed the root box in the last hand-out
                     mr_hit h;
@@ -482,12 +520,12 @@ __global__ __launch_bounds__(kBlock) void trace_persistent_kernel(TraceParams p,
             }
             continue;
         }
-        if (__all(safe_lane || !L.have)) {
-            while (L.have && L.cur >= 0) node_step<EXACT, false, kPersistentSafeSlab, true>(p, r, L, s_stack, tid, st);
+        if (__all(safe_lane || !L.have())) {
+            while (L.cur >= 0) node_step<EXACT, false, kPersistentSafeSlab, true>(p, r, L, s_stack, tid, st);
         } else {
-            while (L.have && L.cur >= 0) node_step<EXACT, false, 0>(p, r, L, s_stack, tid, st);
+            while (L.cur >= 0) node_step<EXACT, false, 0>(p, r, L, s_stack, tid, st);
         }
-        if (L.have) leaf_step<EXACT, ANY, false, true>(p, r, L, s_stack, tid, st);
+        if (L.have()) leaf_step<EXACT, ANY, false, true>(p, r, L, s_stack, tid, st);
     }
 }
 
