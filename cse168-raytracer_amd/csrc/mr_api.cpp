@@ -36,6 +36,8 @@ void release_device(mr_scene *s) {
     DeviceScene &d = s->dev;
     (void)hipFree(d.nodes); (void)hipFree(d.tris); (void)hipFree(d.tri_prim); (void)hipFree(d.leaf_cnt_ext);
     (void)hipFree(d.v); (void)hipFree(d.n); (void)hipFree(d.vi); (void)hipFree(d.ni);
+    (void)hipFree(d.materials); (void)hipFree(d.prim_material);
+    (void)hipFree(d.spheres); (void)hipFree(d.planes);
     d = DeviceScene();
     (void)hipFree(s->d_stats); s->d_stats = nullptr;
     (void)hipFree(s->d_work_counters); s->d_work_counters = nullptr;
@@ -95,6 +97,16 @@ mr_status flatten_and_upload(mr_scene *s) {
     std::vector<uint32_t> cnt_ext(nt, 0);
     for (uint32_t k = 0; k < nt; k++) {
         const uint32_t prim = t.leaf_prims[k];
+        if (m.is_sphere(prim)) {
+            const float *sp = &m.spheres[4 * (size_t)m.vi[3 * (size_t)prim + 1]];
+            uint32_t tag = kSphereTag;
+            float tagf;
+            memcpy(&tagf, &tag, sizeof(tagf));
+            tris[3 * (size_t)k + 0] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+            tris[3 * (size_t)k + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            tris[3 * (size_t)k + 2] = make_float4(0.f, 0.f, 0.f, tagf);
+            continue;
+        }
         const float *A = &m.v[3 * (size_t)m.vi[3 * prim]];
         const float *B = &m.v[3 * (size_t)m.vi[3 * prim + 1]];
         const float *C = &m.v[3 * (size_t)m.vi[3 * prim + 2]];
@@ -118,6 +130,24 @@ mr_status flatten_and_upload(mr_scene *s) {
     if ((st = upload(d.n, m.n.data(), m.n.size(), d.bytes)) != MR_OK) return st;
     if ((st = upload(d.vi, m.vi.data(), m.vi.size(), d.bytes)) != MR_OK) return st;
     if ((st = upload(d.ni, m.ni.data(), m.ni.size(), d.bytes)) != MR_OK) return st;
+    d.n_spheres = m.n_spheres();
+    d.n_planes = m.n_planes();
+    if (d.n_spheres) {
+        std::vector<float4> sp(d.n_spheres);
+        for (uint32_t i = 0; i < d.n_spheres; i++)
+            sp[i] = make_float4(m.spheres[4 * i], m.spheres[4 * i + 1], m.spheres[4 * i + 2], m.spheres[4 * i + 3]);
+        if ((st = upload(d.spheres, sp.data(), sp.size(), d.bytes)) != MR_OK) return st;
+    }
+    if (d.n_planes) {
+        std::vector<float4> pl(2 * (size_t)d.n_planes);
+        for (uint32_t i = 0; i < d.n_planes; i++) {
+            float matf;
+            memcpy(&matf, &m.plane_material[i], sizeof(matf));
+            pl[2 * i] = make_float4(m.planes[6 * i], m.planes[6 * i + 1], m.planes[6 * i + 2], matf);
+            pl[2 * i + 1] = make_float4(m.planes[6 * i + 3], m.planes[6 * i + 4], m.planes[6 * i + 5], 0.f);
+        }
+        if ((st = upload(d.planes, pl.data(), pl.size(), d.bytes)) != MR_OK) return st;
+    }
     const HostNode &root = t.nodes[0];
     memcpy(d.root_lo, root.lo, sizeof(d.root_lo));
     memcpy(d.root_hi, root.hi, sizeof(d.root_hi));
@@ -241,6 +271,31 @@ mr_status mr_scene_add_triangle(mr_scene *s, const float v[9], const float n[9])
     return mr_scene_add_mesh(s, &d);
 }
 
+mr_status mr_scene_add_sphere(mr_scene *s, const float center[3], float radius, uint32_t *prim_out) {
+    if (!s || !center) return fail(MR_ERR_INVALID, "NULL argument");
+    if (s->built) return fail(MR_ERR_STATE, "scene is immutable after mr_bvh_build");
+    HostMesh &m = s->mesh;
+    const uint32_t slot[3] = {kSphereSlot, m.n_spheres(), 0u};
+    if (prim_out) *prim_out = m.n_triangles();
+    m.vi.insert(m.vi.end(), slot, slot + 3);
+    m.ni.insert(m.ni.end(), slot, slot + 3);
+    m.spheres.insert(m.spheres.end(), center, center + 3);
+    m.spheres.push_back(radius);
+    return MR_OK;
+}
+
+mr_status mr_scene_add_plane(mr_scene *s, const float normal[3], const float origin[3], uint32_t material,
+                             uint32_t *index_out) {
+    if (!s || !normal || !origin) return fail(MR_ERR_INVALID, "NULL argument");
+    if (s->built) return fail(MR_ERR_STATE, "scene is immutable after mr_bvh_build");
+    HostMesh &m = s->mesh;
+    if (index_out) *index_out = m.n_planes();
+    m.planes.insert(m.planes.end(), normal, normal + 3);
+    m.planes.insert(m.planes.end(), origin, origin + 3);
+    m.plane_material.push_back(material);
+    return MR_OK;
+}
+
 mr_status mr_bvh_build(mr_scene *s, const mr_build_opts *opts) {
     if (!s) return fail(MR_ERR_INVALID, "scene is NULL");
     uint32_t leaf = 4;
@@ -344,6 +399,7 @@ mr_status mr_trace(mr_scene *s, const mr_ray *rays, uint64_t n, mr_hit *hits, ui
     p.root_ref = s->dev.root_ref;
     p.stack_depth = (int32_t)s->dev.stack_depth;
     p.rays = d_rays; p.hits = d_hits; p.n = n; p.n_dev = nullptr; p.stats = s->d_stats;
+    p.planes = s->dev.planes; p.n_planes = s->dev.n_planes; p.n_spheres = s->dev.n_spheres;
     p.work_counter = s->d_work_counters + (s->next_counter.fetch_add(1) % kWorkCounters);
     if ((st = launch_trace(p, flags, stream)) != MR_OK) return st;
     if (!hits_dev) {
@@ -374,6 +430,7 @@ mr_status mr_trace_indirect(mr_scene *s, const mr_ray *d_rays, const uint64_t *d
     p.rays = d_rays; p.hits = d_hits; p.n = max_rays;
     p.n_dev = reinterpret_cast<const unsigned long long *>(d_count);
     p.stats = s->d_stats;
+    p.planes = s->dev.planes; p.n_planes = s->dev.n_planes; p.n_spheres = s->dev.n_spheres;
     p.work_counter = s->d_work_counters + (s->next_counter.fetch_add(1) % kWorkCounters);
     return launch_trace(p, flags, static_cast<hipStream_t>(stream_v));
 }
@@ -438,6 +495,9 @@ mr_status mr_scene_set_materials(mr_scene *s, const mr_material *mats, uint32_t 
     if (prim_material)
         for (uint32_t i = 0; i < nt; i++)
             if (prim_material[i] >= n_mats) return fail(MR_ERR_INVALID, "triangle %u has material %u of %u", i, prim_material[i], n_mats);
+    for (uint32_t i = 0; i < s->mesh.n_planes(); i++)
+        if (s->mesh.plane_material[i] >= n_mats)
+            return fail(MR_ERR_INVALID, "plane %u has material %u of %u", i, s->mesh.plane_material[i], n_mats);
     s->materials.resize(11 * (size_t)n_mats);
     for (uint32_t i = 0; i < n_mats; i++) {
         float *o = &s->materials[11 * (size_t)i];
@@ -502,12 +562,13 @@ mr_status mr_tonemap(mr_scene *s, const float *d_rgb, uint64_t n_values, uint8_t
     return launch_tonemap(d_rgb, n_values, d_out, static_cast<hipStream_t>(stream));
 }
 
-mr_status mr_hit_attrs(mr_scene *s, const mr_hit *d_hits, uint64_t n, float *d_P, float *d_N, void *stream) {
+mr_status mr_hit_attrs(mr_scene *s, const mr_ray *d_rays, const mr_hit *d_hits, uint64_t n, float *d_P, float *d_N,
+                       void *stream) {
     mr_status st = require_device(s);
     if (st != MR_OK) return st;
     if (!d_hits) return fail(MR_ERR_INVALID, "d_hits is NULL");
     MR_HIP_CHECK(hipSetDevice(s->device));
-    return launch_hit_attrs(s->dev, d_hits, n, d_P, d_N, static_cast<hipStream_t>(stream));
+    return launch_hit_attrs(s->dev, d_rays, d_hits, n, d_P, d_N, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mr_internal.h"
+#include "mr_surface.h"
 
 namespace mr {
 namespace {
@@ -22,29 +23,20 @@ constexpr float kPI = 3.1415926535897932384626433832795028841972f;
 constexpr float kInf = __builtin_huge_valf();
 
 struct MeshMat {
-    const float *v, *n;
-    const uint32_t *vi, *ni;
+    SurfacePtrs s;
     const float *mats;            // 11 floats per material: diffuse, specular, transmission, shininess, index
     const uint32_t *prim_mat;     // NULL: material 0 everywhere
 };
 
 __device__ __forceinline__ const float *material_of(const MeshMat &m, uint32_t prim) {
-    return m.mats + 11 * (size_t)(m.prim_mat ? m.prim_mat[prim] : 0u);
+    return m.mats + 11 * (size_t)material_id(m.s, m.prim_mat, prim);
 }
 __device__ __forceinline__ bool any_pos(const float *c) { return c[0] > 0.f || c[1] > 0.f || c[2] > 0.f; }
 
-// P (Triangle.cpp:160) and the normalised N that Scene::trace hands to its callers (Triangle.cpp:162, Scene.cpp:262)
-__device__ __forceinline__ void surface_point(const MeshMat &m, uint32_t prim, float beta, float gamma, float P[3], float N[3]) {
-    const size_t t3 = 3 * (size_t)prim;
-    const uint32_t ia = m.vi[t3], ib = m.vi[t3 + 1], ic = m.vi[t3 + 2];
-    const uint32_t ja = m.ni[t3], jb = m.ni[t3 + 1], jc = m.ni[t3 + 2];
-    const float alpha = 1 - beta - gamma;
-    for (int c = 0; c < 3; c++) {
-        const float A = m.v[3 * (size_t)ia + c];
-        const float BmA = m.v[3 * (size_t)ib + c] - A, CmA = m.v[3 * (size_t)ic + c] - A;
-        P[c] = (A + beta * BmA) + gamma * CmA;
-        N[c] = (alpha * m.n[3 * (size_t)ja + c] + beta * m.n[3 * (size_t)jb + c]) + gamma * m.n[3 * (size_t)jc + c];
-    }
+// HitInfo::P and the normalised N that Scene::trace hands to its callers (mr_surface.h, Scene.cpp:262)
+__device__ __forceinline__ void surface_point(const MeshMat &m, const mr_ray *rays, unsigned long long k, const float4 h,
+                                              float P[3], float N[3]) {
+    surface<true>(m.s, rays, k, h.x, __float_as_uint(h.y), h.z, h.w, P, N);
     const float inv = 1.0f / sqrtf((N[0] * N[0] + N[1] * N[1]) + N[2] * N[2]);
     N[0] *= inv; N[1] *= inv; N[2] *= inv;
 }
@@ -64,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void light_scale_kernel(MeshMat m, const mr
             const float *om = material_of(m, prim);
             if (any_pos(om + 6)) {                                    // refractive occluder (Phong.cpp:99-113)
                 float P[3], N[3];
-                surface_point(m, prim, h.z, h.w, P, N);
+                surface_point(m, shadow_rays, k, h, P, N);
                 const float4 rb = reinterpret_cast<const float4 *>(shadow_rays)[2 * k + 1];
                 const float d = (N[0] * rb.x + N[1] * rb.y) + N[2] * rb.z;
                 if (!(d < 0) && !(d < kEps)) scale = d;
@@ -98,7 +90,7 @@ __global__ __launch_bounds__(kBlock) void shade_accumulate_kernel(AccumArgs a) {
         if (scale != 0.0f) {
             const float *mt = material_of(a.m, prim);
             float P[3], N[3];
-            surface_point(a.m, prim, h.z, h.w, P, N);
+            surface_point(a.m, a.rays, k, h, P, N);
             float l[3] = {a.L[0] - P[0], a.L[1] - P[1], a.L[2] - P[2]};
             const float falloff = (l[0] * l[0] + l[1] * l[1]) + l[2] * l[2];
             const float inv = 1.0f / sqrtf(falloff);
@@ -164,7 +156,7 @@ __global__ __launch_bounds__(kBlock) void secondary_rays_kernel(BounceArgs a) {
                 const bool refl = any_pos(mt + 3), refr = any_pos(mt + 6);
                 if (refl || refr) {
                     float P[3], N[3];
-                    surface_point(a.m, prim, h.z, h.w, P, N);
+                    surface_point(a.m, a.rays, k, h, P, N);
                     const float4 rb = reinterpret_cast<const float4 *>(a.rays)[2 * k + 1];
                     const float d[3] = {rb.x, rb.y, rb.z};
                     float w0[3] = {1.f, 1.f, 1.f};
@@ -243,7 +235,7 @@ inline unsigned grid_for(unsigned long long n) {
 
 MeshMat mesh_of(const DeviceScene &ds) {
     MeshMat m;
-    m.v = ds.v; m.n = ds.n; m.vi = ds.vi; m.ni = ds.ni; m.mats = ds.materials; m.prim_mat = ds.prim_material;
+    m.s = surface_ptrs(ds); m.mats = ds.materials; m.prim_mat = ds.prim_material;
     return m;
 }
 

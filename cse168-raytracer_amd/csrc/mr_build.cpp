@@ -53,10 +53,15 @@ public:
         const uint32_t nt = mesh.n_triangles();
         prims_.resize(nt);
         for (uint32_t i = 0; i < nt; i++) {
+            PrimRef &p = prims_[i];
+            if (mesh.is_sphere(i)) {      // Sphere.h:19-21: m_center -/+ Vector3(m_radius), centre = m_center
+                const float *sp = &mesh.spheres[4 * (size_t)mesh.vi[3 * (size_t)i + 1]];
+                for (int k = 0; k < 3; k++) { p.lo[k] = sp[k] - sp[3]; p.hi[k] = sp[k] + sp[3]; p.ctr[k] = sp[k]; }
+                continue;
+            }
             const float *a = &mesh.v[3 * (size_t)mesh.vi[3 * i + 0]];
             const float *b = &mesh.v[3 * (size_t)mesh.vi[3 * i + 1]];
             const float *c = &mesh.v[3 * (size_t)mesh.vi[3 * i + 2]];
-            PrimRef &p = prims_[i];
             const float third = 1.0f / 3.0f;      // Vector3::operator/(3): multiply by rounded 1/3
             for (int k = 0; k < 3; k++) {
                 float mn = a[k], mx = a[k];

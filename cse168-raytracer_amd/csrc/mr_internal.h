@@ -40,12 +40,26 @@ struct HostTree {
     uint32_t n_leaves = 0, max_depth = 0, leaf_size = 4;
 };
 
+// Bounded objects in Scene::addObject order (Scene.h:20-25).  Object i is a triangle with indices vi/ni[3i..3i+2]
+// or, when vi[3i] == kSphereSlot, the sphere number vi[3i+1] (a Sphere takes the next object index like any
+// triangle would).  Planes are unbounded (Plane.h:27): they never enter the BVH and are scanned after it
+// (Scene.cpp:220-230); a hit on plane k reports prim = kPlaneBit | k.
+constexpr uint32_t kSphereSlot = 0xFFFFFFFFu;
+constexpr uint32_t kPlaneBit = 0x80000000u;
+constexpr uint32_t kSphereTag = 0x7fc00168u;   // bits of q2.w of a sphere's 48-byte leaf record (a NaN no product yields)
+
 struct HostMesh {
     std::vector<float> v, n;        // xyz triples
-    std::vector<uint32_t> vi, ni;   // 3 per triangle
+    std::vector<uint32_t> vi, ni;   // 3 per object
+    std::vector<float> spheres;     // cx, cy, cz, radius
+    std::vector<float> planes;      // normal xyz, origin xyz
+    std::vector<uint32_t> plane_material;
     uint32_t n_vertices() const { return (uint32_t)(v.size() / 3); }
     uint32_t n_normals() const { return (uint32_t)(n.size() / 3); }
-    uint32_t n_triangles() const { return (uint32_t)(vi.size() / 3); }
+    uint32_t n_triangles() const { return (uint32_t)(vi.size() / 3); }      // objects: triangles + spheres
+    uint32_t n_spheres() const { return (uint32_t)(spheres.size() / 4); }
+    uint32_t n_planes() const { return (uint32_t)(planes.size() / 6); }
+    bool is_sphere(uint32_t obj) const { return !spheres.empty() && vi[3 * (size_t)obj] == kSphereSlot; }
 };
 
 // TriangleMesh::load semantics (TriangleMeshLoad.cpp:63-311): appends to `mesh`
@@ -65,6 +79,8 @@ mr_status build_reference_tree(const HostMesh &mesh, uint32_t leaf_size, HostTre
 // count == 15 means "read leaf_cnt_ext[first]" (only leaves cut off at depth 32 get there).
 // Triangle k (leaf order) = 3 consecutive float4 (48 bytes):
 //   (A.x, A.y, A.z, BmA.x) (BmA.y, BmA.z, CmA.x, CmA.y) (CmA.z, n.x, n.y, n.z),  n = BmA x CmA
+// A sphere's record in the same array: (c.x, c.y, c.z, radius) (0, 0, 0, 0) (0, 0, 0, kSphereTag bits).
+// Plane k = 2 float4: (normal.xyz, material id bits) (origin.xyz, 0).
 constexpr int kLeafCountBits = 4;
 constexpr int kLeafCountMask = 15;
 constexpr uint32_t kWorkCounters = 64;   // launches in flight on different streams each get their own counter
@@ -81,6 +97,9 @@ struct DeviceScene {
     // every triangle; prim_material == nullptr means material 0 everywhere
     float    *materials = nullptr;
     uint32_t *prim_material = nullptr;
+    float4   *spheres = nullptr;       // (c.xyz, radius) per sphere; nullptr when the scene has none
+    float4   *planes = nullptr;        // 2 per plane; nullptr when the scene has none
+    uint32_t n_spheres = 0, n_planes = 0;
     float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
     int32_t root_ref = 0;
     uint32_t n_inner = 0, n_tris = 0, stack_depth = 1;
@@ -100,6 +119,8 @@ struct TraceParams {
     unsigned long long n;                 // number of rays (upper bound when n_dev is set)
     const unsigned long long *n_dev;      // optional device-resident ray count (mr_trace_indirect)
     unsigned long long *stats;   // [0] box tests, [1] triangle tests (MR_COUNT_STATS)
+    const float4 *planes;                 // unbounded objects, scanned after the BVH (Scene.cpp:220-230)
+    uint32_t n_planes, n_spheres;
     unsigned long long *work_counter;     // zeroed per launch: ray hand-out counter of the persistent kernel
 };
 
@@ -109,7 +130,7 @@ mr_status launch_eye_rays(const mr_camera &cam, uint32_t W, uint32_t H, uint32_t
 mr_status launch_shadow_rays(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits,
                              unsigned long long n, const float light[3], mr_ray *d_out, uint32_t *d_src,
                              unsigned long long *d_count, hipStream_t stream);
-mr_status launch_hit_attrs(const DeviceScene &ds, const mr_hit *d_hits, unsigned long long n,
+mr_status launch_hit_attrs(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits, unsigned long long n,
                            float *d_P, float *d_N, hipStream_t stream);
 
 mr_status launch_shade(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits, unsigned long long n,

@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "mr_internal.h"
+#include "mr_surface.h"
 
 namespace mr {
 namespace {
@@ -168,6 +169,33 @@ __device__ __forceinline__ bool tri_test(const float4 q0, const float4 q1, const
     return !reject;
 }
 
+// Sphere::intersect (Sphere.cpp:28-69) on the record (c.xyz, radius): the quadratic in the reference's order of
+// operations, true divisions, strict range test on both roots.
+__device__ __forceinline__ bool sphere_test(const float4 q0, const RayRegs &r, float tmax, float &t) {
+    const float tx = r.ox - q0.x, ty = r.oy - q0.y, tz = r.oz - q0.z;       // toO = ray.o - m_center
+    const float a = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz;               // ray.d.length2()
+    const float b = ((r.dx * 2) * tx + (r.dy * 2) * ty) + (r.dz * 2) * tz;   // dot(2*ray.d, toO)
+    const float c = ((tx * tx + ty * ty) + tz * tz) - q0.w * q0.w;
+    const float discrim = b * b - 4.0f * a * c;
+    if (discrim < 0) return false;
+    const float sq = sqrtf(discrim);
+    const float t0 = (-b - sq) / (2.0f * a), t1 = (-b + sq) / (2.0f * a);
+    if ((t0 > r.tmin) && (t0 < tmax)) { t = t0; return true; }
+    if ((t1 > r.tmin) && (t1 < tmax)) { t = t1; return true; }
+    return false;
+}
+
+// the object test of a leaf slot: Triangle::intersect, or Sphere::intersect when OBJ and the record carries the tag
+template <bool EXACT, bool OBJ>
+__device__ __forceinline__ bool object_test(const float4 q0, const float4 q1, const float4 q2, const RayRegs &r,
+                                            float tmax, float &t, float &beta, float &gamma) {
+    if (OBJ && __float_as_uint(q2.w) == kSphereTag) {
+        beta = 0.0f; gamma = 0.0f;
+        return sphere_test(q0, r, tmax, t);
+    }
+    return tri_test<EXACT>(q0, q1, q2, r, tmax, t, beta, gamma);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // closest-hit / any-hit traversal, one ray per lane.
 // VAR bit 0: when no lane of the wave can produce a NaN in a slab product (o, d, 1/d all finite -- wave-uniform
@@ -301,7 +329,7 @@ __device__ __forceinline__ void load_tri_scalar(const float4 *tris, unsigned pos
     q2 = make_float4(c[0], c[1], c[2], c[3]);
 }
 
-template <bool EXACT, bool ANY, bool STATS, bool SCALAR = false>
+template <bool EXACT, bool ANY, bool STATS, bool SCALAR = false, bool OBJ = false>
 __device__ __forceinline__ void leaf_step(const TraceParams &p, const RayRegs &r, Lane &L, int *s_stack, int tid, Stats &st) {
     // ---- leaf (BVH.cpp:493-509)
     const unsigned bits = ~(unsigned)L.cur;
@@ -321,7 +349,7 @@ __device__ __forceinline__ void leaf_step(const TraceParams &p, const RayRegs &r
                 load_tri_scalar(p.tris, first0 + k, q0, q1, q2);
                 if (!(ANY && done)) {
                     float t, b, g;
-                    const bool ok = tri_test<EXACT>(q0, q1, q2, r, L.best_t, t, b, g);
+                    const bool ok = object_test<EXACT, OBJ>(q0, q1, q2, r, L.best_t, t, b, g);
                     if (ok && t < L.best_t) {
                         L.best_t = t; L.best_b = b; L.best_g = g; L.best_pos = (int)(first0 + k);
                         if (ANY) done = true;
@@ -334,7 +362,7 @@ __device__ __forceinline__ void leaf_step(const TraceParams &p, const RayRegs &r
         for (unsigned k = 0; k < cnt; k++) {
             const float4 *tr = p.tris + 3 * (size_t)(first + k);
             float t, b, g;
-            const bool ok = tri_test<EXACT>(tr[0], tr[1], tr[2], r, L.best_t, t, b, g);
+            const bool ok = object_test<EXACT, OBJ>(tr[0], tr[1], tr[2], r, L.best_t, t, b, g);
             if (ok && t < L.best_t) {             // strict-less replacement (:500)
                 L.best_t = t; L.best_b = b; L.best_g = g; L.best_pos = (int)(first + k);
                 if (ANY) { done = true; break; }
@@ -350,17 +378,17 @@ __device__ __forceinline__ void leaf_step(const TraceParams &p, const RayRegs &r
     }
 }
 
-template <bool EXACT, bool ANY, bool STATS, int SLAB, bool WW, bool SCALAR>
+template <bool EXACT, bool ANY, bool STATS, int SLAB, bool WW, bool SCALAR, bool OBJ = false>
 __device__ __forceinline__ void traverse(const TraceParams &p, const RayRegs &r, Lane &L, int *s_stack, int tid, Stats &st) {
     if (WW) {
         while (__any(L.have())) {
             while (L.cur >= 0) node_step<EXACT, STATS, SLAB, SCALAR>(p, r, L, s_stack, tid, st);
-            if (L.have()) leaf_step<EXACT, ANY, STATS, SCALAR>(p, r, L, s_stack, tid, st);
+            if (L.have()) leaf_step<EXACT, ANY, STATS, SCALAR, OBJ>(p, r, L, s_stack, tid, st);
         }
     } else {
         while (L.have()) {
             if (L.cur >= 0) node_step<EXACT, STATS, SLAB, SCALAR>(p, r, L, s_stack, tid, st);
-            else leaf_step<EXACT, ANY, STATS, false>(p, r, L, s_stack, tid, st);
+            else leaf_step<EXACT, ANY, STATS, false, OBJ>(p, r, L, s_stack, tid, st);
         }
     }
 }
@@ -375,6 +403,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(TraceParams p) {
     constexpr bool kWW = (VAR & 2) != 0;
     constexpr int kSafeSlab = (VAR & 4) ? 2 : 1;      // slab form for waves whose rays cannot produce a NaN
     constexpr bool kScalar = (VAR & 8) != 0;          // wave-uniform nodes through the scalar cache
+    constexpr bool kObj = (VAR & 32) != 0;            // the scene holds spheres and / or planes
 
     // indirect batches: the ray count lives on the device (e.g. written by the shadow-ray compaction)
     unsigned long long n_rays = p.n;
@@ -410,15 +439,31 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(TraceParams p) {
         if (kMinMax) {
             // a slab product (corner - o) * (1/d) can only be NaN as 0*inf or inf*0 or from a non-finite origin:
             // with o, d and 1/d all finite in every lane the select form and the min/max form decide identically
-            if (__all(lane_is_nan_free(r) || !live)) traverse<EXACT, ANY, STATS, kSafeSlab, kWW, kScalar>(p, r, L, s_stack, tid, st);
-            else traverse<EXACT, ANY, STATS, 0, kWW, false>(p, r, L, s_stack, tid, st);
+            if (__all(lane_is_nan_free(r) || !live)) traverse<EXACT, ANY, STATS, kSafeSlab, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
+            else traverse<EXACT, ANY, STATS, 0, kWW, false, kObj>(p, r, L, s_stack, tid, st);
         } else {
-            traverse<EXACT, ANY, STATS, 0, kWW, false>(p, r, L, s_stack, tid, st);
+            traverse<EXACT, ANY, STATS, 0, kWW, false, kObj>(p, r, L, s_stack, tid, st);
+        }
+
+        // Scene::trace's scan of the unbounded objects (Scene.cpp:220-230): every plane is tested against the
+        // caller's tMin / tMax (Plane.cpp:33-48) and kept when nothing was hit yet or it is strictly nearer
+        int plane_hit = -1;
+        if (kObj && live && !(ANY && L.best_pos >= 0)) {
+            for (uint32_t k = 0; k < p.n_planes; k++) {
+                const float4 pn = p.planes[2 * k], po = p.planes[2 * k + 1];
+                const float ndotd = (pn.x * r.dx + pn.y * r.dy) + pn.z * r.dz;
+                if ((double)__builtin_fabsf(ndotd) < 1e-6) continue;          // fabs(float) < double literal
+                const float t = ((pn.x * (po.x - r.ox) + pn.y * (po.y - r.oy)) + pn.z * (po.z - r.oz)) / ndotd;
+                if (t < r.tmin || t > tmax0) continue;
+                if ((L.best_pos < 0 && plane_hit < 0) || t < L.best_t) { L.best_t = t; plane_hit = (int)k; }
+            }
         }
 
         if (live) {
             mr_hit h;
-            if (L.best_pos >= 0) {
+            if (kObj && plane_hit >= 0) {
+                h.t = L.best_t; h.prim = kPlaneBit | (uint32_t)plane_hit; h.beta = 0.0f; h.gamma = 0.0f;
+            } else if (L.best_pos >= 0) {
                 h.t = L.best_t; h.prim = p.tri_prim[L.best_pos]; h.beta = L.best_b; h.gamma = L.best_g;
             } else {
                 h.t = tmax0; h.prim = MR_MISS; h.beta = 0.0f; h.gamma = 0.0f;
@@ -579,19 +624,6 @@ __global__ __launch_bounds__(kBlock) void eye_rays_kernel(EyeFrame f, mr_ray *ra
 // Hits are compacted wave-by-wave: ballot of hitting lanes, one atomicAdd per wave for the base,
 // mbcnt prefix for the lane's slot.
 // ---------------------------------------------------------------------------------------------------
-struct MeshPtrs { const float *v, *n; const uint32_t *vi, *ni; };
-
-__device__ __forceinline__ void hit_point(const MeshPtrs &m, uint32_t prim, float beta, float gamma,
-                                          float &Px, float &Py, float &Pz) {
-    const uint32_t ia = m.vi[3 * (size_t)prim], ib = m.vi[3 * (size_t)prim + 1], ic = m.vi[3 * (size_t)prim + 2];
-    const float ax = m.v[3 * (size_t)ia], ay = m.v[3 * (size_t)ia + 1], az = m.v[3 * (size_t)ia + 2];
-    const float bx = m.v[3 * (size_t)ib] - ax, by = m.v[3 * (size_t)ib + 1] - ay, bz = m.v[3 * (size_t)ib + 2] - az;
-    const float cx = m.v[3 * (size_t)ic] - ax, cy = m.v[3 * (size_t)ic + 1] - ay, cz = m.v[3 * (size_t)ic + 2] - az;
-    Px = (ax + beta * bx) + gamma * cx;               // A + beta*BmA + gamma*CmA (Triangle.cpp:160)
-    Py = (ay + beta * by) + gamma * cy;
-    Pz = (az + beta * bz) + gamma * cz;
-}
-
 // Compaction is hierarchical so that the global counter sees one atomic per 2048 rays, not one per wave
 // (a single counter word saturates at ~88 atomics/us, MI355X_MICROARCH.md "dequeue"): each workgroup takes
 // chunks of kBlock*kShIter rays; every wave ballots its kShIter sub-rows (wave64 __ballot + popcount
@@ -599,7 +631,7 @@ __device__ __forceinline__ void hit_point(const MeshPtrs &m, uint32_t prim, floa
 // writes at  chunk base + waves before mine + sub-rows before this one + lanes before mine.
 constexpr int kShIter = 8;
 
-__global__ __launch_bounds__(kBlock) void shadow_rays_kernel(MeshPtrs m, const mr_hit *hits, unsigned long long n,
+__global__ __launch_bounds__(kBlock) void shadow_rays_kernel(SurfacePtrs m, const mr_ray *rays, const mr_hit *hits, unsigned long long n,
                                                              float Lx, float Ly, float Lz, mr_ray *out,
                                                              uint32_t *src, unsigned long long *count) {
     __shared__ unsigned s_wave_total[kBlock / 64];
@@ -639,8 +671,9 @@ __global__ __launch_bounds__(kBlock) void shadow_rays_kernel(MeshPtrs m, const m
             if (__float_as_uint(h[it].y) == MR_MISS) continue;
             const unsigned long long k = c * chunk + (unsigned long long)it * kBlock + threadIdx.x;
             const unsigned long long slot = wave_base + prefix[it];
-            float Px, Py, Pz;
-            hit_point(m, __float_as_uint(h[it].y), h[it].z, h[it].w, Px, Py, Pz);
+            float P[3];
+            surface<false>(m, rays, k, h[it].x, __float_as_uint(h[it].y), h[it].z, h[it].w, P, nullptr);
+            const float Px = P[0], Py = P[1], Pz = P[2];
             float lx = Lx - Px, ly = Ly - Py, lz = Lz - Pz;           // PointLight::getLightDirection
             const float falloff = (lx * lx + ly * ly) + lz * lz;
             const float len = sqrtf(falloff);
@@ -656,24 +689,16 @@ __global__ __launch_bounds__(kBlock) void shadow_rays_kernel(MeshPtrs m, const m
     }
 }
 
-__global__ __launch_bounds__(kBlock) void hit_attrs_kernel(MeshPtrs m, const mr_hit *hits, unsigned long long n,
-                                                           float *P, float *N) {
+__global__ __launch_bounds__(kBlock) void hit_attrs_kernel(SurfacePtrs m, const mr_ray *rays, const mr_hit *hits,
+                                                           unsigned long long n, float *P, float *N) {
     const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
     for (unsigned long long k = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; k < n; k += stride) {
         const float4 h = reinterpret_cast<const float4 *>(hits)[k];
         const uint32_t prim = __float_as_uint(h.y);
-        float Px = 0.f, Py = 0.f, Pz = 0.f, Nx = 0.f, Ny = 1.f, Nz = 0.f;     // HitInfo defaults (Ray.h:31-34)
-        if (prim != MR_MISS) {
-            const float beta = h.z, gamma = h.w;
-            hit_point(m, prim, beta, gamma, Px, Py, Pz);
-            const uint32_t ia = m.ni[3 * (size_t)prim], ib = m.ni[3 * (size_t)prim + 1], ic = m.ni[3 * (size_t)prim + 2];
-            const float alpha = 1 - beta - gamma;
-            Nx = (alpha * m.n[3 * (size_t)ia]     + beta * m.n[3 * (size_t)ib])     + gamma * m.n[3 * (size_t)ic];
-            Ny = (alpha * m.n[3 * (size_t)ia + 1] + beta * m.n[3 * (size_t)ib + 1]) + gamma * m.n[3 * (size_t)ic + 1];
-            Nz = (alpha * m.n[3 * (size_t)ia + 2] + beta * m.n[3 * (size_t)ib + 2]) + gamma * m.n[3 * (size_t)ic + 2];
-        }
-        if (P) { P[3 * k] = Px; P[3 * k + 1] = Py; P[3 * k + 2] = Pz; }
-        if (N) { N[3 * k] = Nx; N[3 * k + 1] = Ny; N[3 * k + 2] = Nz; }
+        float Pv[3] = {0.f, 0.f, 0.f}, Nv[3] = {0.f, 1.f, 0.f};               // HitInfo defaults (Ray.h:31-34)
+        if (prim != MR_MISS) surface<true>(m, rays, k, h.x, prim, h.z, h.w, Pv, Nv);
+        if (P) { P[3 * k] = Pv[0]; P[3 * k + 1] = Pv[1]; P[3 * k + 2] = Pv[2]; }
+        if (N) { N[3 * k] = Nv[0]; N[3 * k + 1] = Nv[1]; N[3 * k + 2] = Nv[2]; }
     }
 }
 
@@ -769,6 +794,12 @@ static mr_status launch_exact(const TraceParams &p, hipStream_t stream) {
 mr_status launch_trace(const TraceParams &p, uint32_t flags, hipStream_t stream) {
     if (p.n == 0) return MR_OK;
     const bool fast = flags & MR_MATH_FAST, any = flags & MR_TRACE_ANY, stats = flags & MR_COUNT_STATS;
+    if (p.n_planes || p.n_spheres) {
+        // scenes with spheres / planes: the exact kernel with the object dispatch compiled in (VAR bit 5); the fast
+        // and persistent forms cover triangle scenes only
+        if (stats) return any ? launch_trace_t<true, true, true, 32>(p, stream) : launch_trace_t<true, false, true, 32>(p, stream);
+        return any ? launch_trace_t<true, true, false, 43>(p, stream) : launch_trace_t<true, false, false, 43>(p, stream);
+    }
     if (stats) {
         // counting mode is diagnostic: always the strict-division exact kernel in the reference's control flow
         return any ? launch_trace_t<true, true, true, 0>(p, stream) : launch_trace_t<true, false, true, 0>(p, stream);
@@ -818,23 +849,25 @@ mr_status launch_eye_rays(const mr_camera &cam, uint32_t W, uint32_t H, uint32_t
     return MR_OK;
 }
 
-mr_status launch_shadow_rays(const DeviceScene &ds, const mr_ray *, const mr_hit *d_hits, unsigned long long n,
+mr_status launch_shadow_rays(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits, unsigned long long n,
                              const float light[3], mr_ray *d_out, uint32_t *d_src, unsigned long long *d_count,
                              hipStream_t stream) {
     MR_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), stream));
     if (n == 0) return MR_OK;
-    MeshPtrs m{ds.v, ds.n, ds.vi, ds.ni};
-    hipLaunchKernelGGL(shadow_rays_kernel, dim3(grid_for(n)), dim3(kBlock), 0, stream, m, d_hits, n,
+    if ((ds.spheres || ds.planes) && !d_rays)
+        return fail(MR_ERR_INVALID, "the scene holds spheres / planes: their hit point is o + t*d, d_rays is required");
+    hipLaunchKernelGGL(shadow_rays_kernel, dim3(grid_for(n)), dim3(kBlock), 0, stream, surface_ptrs(ds), d_rays, d_hits, n,
                        light[0], light[1], light[2], d_out, d_src, d_count);
     MR_HIP_CHECK(hipGetLastError());
     return MR_OK;
 }
 
-mr_status launch_hit_attrs(const DeviceScene &ds, const mr_hit *d_hits, unsigned long long n, float *d_P, float *d_N,
-                           hipStream_t stream) {
+mr_status launch_hit_attrs(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits, unsigned long long n,
+                           float *d_P, float *d_N, hipStream_t stream) {
     if (n == 0) return MR_OK;
-    MeshPtrs m{ds.v, ds.n, ds.vi, ds.ni};
-    hipLaunchKernelGGL(hit_attrs_kernel, dim3(grid_for(n)), dim3(kBlock), 0, stream, m, d_hits, n, d_P, d_N);
+    if ((ds.spheres || ds.planes) && !d_rays)
+        return fail(MR_ERR_INVALID, "the scene holds spheres / planes: their hit point is o + t*d, d_rays is required");
+    hipLaunchKernelGGL(hit_attrs_kernel, dim3(grid_for(n)), dim3(kBlock), 0, stream, surface_ptrs(ds), d_rays, d_hits, n, d_P, d_N);
     MR_HIP_CHECK(hipGetLastError());
     return MR_OK;
 }

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mr_internal.h"
+#include "mr_surface.h"
 
 namespace mr {
 namespace {
@@ -28,8 +29,7 @@ __global__ __launch_bounds__(kBlock) void occlusion_scatter_kernel(const mr_hit 
 }
 
 struct ShadeArgs {
-    const float *v, *n;
-    const uint32_t *vi, *ni;
+    SurfacePtrs m;
     const mr_ray *rays;
     const mr_hit *hits;
     const uint8_t *occluded;
@@ -46,18 +46,8 @@ __device__ __forceinline__ void shade_sample(const ShadeArgs &a, unsigned long l
     if (prim == MR_MISS) { out[0] = a.bg[0]; out[1] = a.bg[1]; out[2] = a.bg[2]; return; }   // Scene.cpp:340
     out[0] = out[1] = out[2] = 0.0f;
     if (a.occluded[k]) return;                                                              // Phong.cpp:97-100
-    const float beta = h.z, gamma = h.w;
-    const size_t t3 = 3 * (size_t)prim;
-    const uint32_t ia = a.vi[t3], ib = a.vi[t3 + 1], ic = a.vi[t3 + 2];
-    const uint32_t ja = a.ni[t3], jb = a.ni[t3 + 1], jc = a.ni[t3 + 2];
     float P[3], N[3];
-    const float alpha = 1 - beta - gamma;
-    for (int c = 0; c < 3; c++) {
-        const float A = a.v[3 * (size_t)ia + c];
-        const float BmA = a.v[3 * (size_t)ib + c] - A, CmA = a.v[3 * (size_t)ic + c] - A;
-        P[c] = (A + beta * BmA) + gamma * CmA;                                               // Triangle.cpp:160
-        N[c] = (alpha * a.n[3 * (size_t)ja + c] + beta * a.n[3 * (size_t)jb + c]) + gamma * a.n[3 * (size_t)jc + c];
-    }
+    surface<true>(a.m, a.rays, k, h.x, prim, h.z, h.w, P, N);                               // HitInfo::P, ::N
     {   // Scene.cpp:262 -- N.normalize()
         const float inv = 1.0f / sqrtf((N[0] * N[0] + N[1] * N[1]) + N[2] * N[2]);
         N[0] *= inv; N[1] *= inv; N[2] *= inv;
@@ -153,7 +143,7 @@ mr_status launch_shade(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit
                        d_shadow_count, n, d_occluded);
     MR_HIP_CHECK(hipGetLastError());
     ShadeArgs a;
-    a.v = ds.v; a.n = ds.n; a.vi = ds.vi; a.ni = ds.ni;
+    a.m = surface_ptrs(ds);
     a.rays = d_rays; a.hits = d_hits; a.occluded = d_occluded;
     for (int c = 0; c < 3; c++) { a.L[c] = light.position[c]; a.color[c] = light.color[c]; a.diffuse[c] = diffuse[c]; a.bg[c] = 0.0f; }
     a.wattage = light.wattage;

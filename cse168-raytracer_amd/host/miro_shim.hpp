@@ -12,7 +12,8 @@
 // Header-only, C++11, links against libmiro_hip.so only.  What is restated here from the reference:
 // the value types (Vector3 subset, Ray, HitInfo, Ray.h:21-84), TriangleMesh/Triangle as data carriers
 // (TriangleMesh.h:9-69, Triangle.h:12-45), HitInfo reconstruction P, N (Triangle.cpp:160-166) and
-// Scene::trace's normal normalisation (Scene.cpp:262).  Nothing is intersected on the CPU.
+// Scene::trace's normal normalisation (Scene.cpp:262), Sphere / Plane as data carriers with their P, N
+// (Sphere.cpp:61-63, Plane.cpp:42-44).  Nothing is intersected on the CPU.
 #pragma once
 
 #include <cmath>
@@ -116,6 +117,31 @@ private:
     unsigned int m_index;
 };
 
+// Sphere (Sphere.h:8-36) and Plane (Plane.h:12-34) as data carriers: intersected on the device
+class Sphere : public Object {
+public:
+    Sphere() : m_center(), m_radius(0.0f) {}              // m_center = Vector3() = (0,1,2), sic
+    void setCenter(const Vector3 &v) { m_center = v; }
+    void setRadius(const float f) { m_radius = f; }
+    const Vector3 &center() const { return m_center; }
+    float radius() const { return m_radius; }
+protected:
+    Vector3 m_center;
+    float m_radius;
+};
+
+class Plane : public Object {
+public:
+    Plane() : m_normal(0, 1, 0), m_origin(0, 0, 0) {}     // Plane.cpp:7-11
+    void setNormal(Vector3 normal) { m_normal = normal; }
+    void setOrigin(Vector3 origin) { m_origin = origin; }
+    const Vector3 &normal() const { return m_normal; }
+    const Vector3 &origin() const { return m_origin; }
+    virtual bool isBounded() const { return false; }      // Plane.h:27
+protected:
+    Vector3 m_normal, m_origin;
+};
+
 class Ray {                                               // Ray.h:40-84
 public:
     bool isDiffuse;
@@ -145,40 +171,68 @@ inline void check(mr_status s) { if (s != MR_OK) throw MiroHipError(s, mr_last_e
 // uploads their triangles; intersect() is a closest-hit query on the device.
 class BVH {
 public:
-    BVH() : m_scene(0), m_objs(0), m_device(0) {}
+    BVH() : m_scene(0), m_objs(0), m_unbounded(0), m_device(0) {}
     ~BVH() { if (m_scene) mr_scene_destroy(m_scene); }
     void setDevice(int device) { m_device = device; }
+    // Scene::m_unboundedObjects (Scene.h:22-23): scanned by the device after the BVH, as Scene::trace does
+    // (Scene.cpp:220-230).  Call before build(); BVH::intersect on its own knows no unbounded objects.
+    void setUnbounded(Objects *objs) { m_unbounded = objs; }
 
     void build(Objects *objs, int /*depth*/ = 0) {
         if (m_scene) { mr_scene_destroy(m_scene); m_scene = 0; }
         m_objs = objs;
         m_flat.clear();
         check(mr_scene_create(m_device, &m_scene));
-        // one mesh of 3 vertices + 3 normals per object, in addObject order: prim index == object index
+        // objects go over in addObject order, so that prim index == object index: runs of triangles as meshes of
+        // 3 vertices + 3 normals per triangle, spheres one by one
         const size_t n = objs->size();
-        std::vector<float> v(9 * n), nn(9 * n);
-        std::vector<uint32_t> idx(3 * n);
+        std::vector<float> v, nn;
+        std::vector<uint32_t> idx;
         m_flat.resize(n);
+        struct Flush {
+            static void run(mr_scene *sc, std::vector<float> &v, std::vector<float> &nn, std::vector<uint32_t> &idx) {
+                if (idx.empty()) return;
+                mr_mesh_desc d;
+                d.vertices = v.data(); d.n_vertices = (uint32_t)(v.size() / 3);
+                d.normals = nn.data(); d.n_normals = (uint32_t)(nn.size() / 3);
+                d.vidx = idx.data(); d.nidx = idx.data(); d.n_triangles = (uint32_t)(idx.size() / 3);
+                check(mr_scene_add_mesh(sc, &d));
+                v.clear(); nn.clear(); idx.clear();
+            }
+        };
         for (size_t i = 0; i < n; i++) {
+            Flat &f = m_flat[i];
+            if (Sphere *sp = dynamic_cast<Sphere *>((*objs)[i])) {
+                Flush::run(m_scene, v, nn, idx);
+                const float c[3] = {sp->center().x, sp->center().y, sp->center().z};
+                uint32_t prim = 0;
+                check(mr_scene_add_sphere(m_scene, c, sp->radius(), &prim));
+                if (prim != i) throw MiroHipError(MR_ERR_STATE, "object order lost");
+                f.sphere = true; f.A = sp->center();
+                continue;
+            }
             Triangle *t = dynamic_cast<Triangle *>((*objs)[i]);
-            if (!t) throw MiroHipError(MR_ERR_INVALID, "only Triangle objects are traced on the device (spheres/planes stay on the host path)");
+            if (!t) throw MiroHipError(MR_ERR_INVALID, "bounded objects must be Triangle or Sphere");
             const TriangleMesh *m = t->getMesh();
             const unsigned *vi = m->vIndices(t->getIndex()), *ni = m->nIndices(t->getIndex());
             for (int k = 0; k < 3; k++) {
                 Vector3 p = m->vertex(vi[k]), q = m->normal(ni[k]);
-                v[9 * i + 3 * k] = p.x; v[9 * i + 3 * k + 1] = p.y; v[9 * i + 3 * k + 2] = p.z;
-                nn[9 * i + 3 * k] = q.x; nn[9 * i + 3 * k + 1] = q.y; nn[9 * i + 3 * k + 2] = q.z;
-                idx[3 * i + k] = (uint32_t)(3 * i + k);
+                idx.push_back((uint32_t)(v.size() / 3));
+                v.push_back(p.x); v.push_back(p.y); v.push_back(p.z);
+                nn.push_back(q.x); nn.push_back(q.y); nn.push_back(q.z);
             }
-            Flat &f = m_flat[i];
+            f.sphere = false;
             f.A = m->vertex(vi[0]); f.BmA = m->vertex(vi[1]) - f.A; f.CmA = m->vertex(vi[2]) - f.A;
             f.nA = m->normal(ni[0]); f.nB = m->normal(ni[1]); f.nC = m->normal(ni[2]);
         }
-        mr_mesh_desc d;
-        d.vertices = v.data(); d.n_vertices = (uint32_t)(3 * n);
-        d.normals = nn.data(); d.n_normals = (uint32_t)(3 * n);
-        d.vidx = idx.data(); d.nidx = idx.data(); d.n_triangles = (uint32_t)n;
-        check(mr_scene_add_mesh(m_scene, &d));
+        Flush::run(m_scene, v, nn, idx);
+        for (size_t i = 0; m_unbounded && i < m_unbounded->size(); i++) {
+            Plane *pl = dynamic_cast<Plane *>((*m_unbounded)[i]);
+            if (!pl) throw MiroHipError(MR_ERR_INVALID, "unbounded objects must be Plane");
+            const float nrm[3] = {pl->normal().x, pl->normal().y, pl->normal().z};
+            const float org[3] = {pl->origin().x, pl->origin().y, pl->origin().z};
+            check(mr_scene_add_plane(m_scene, nrm, org, 0, 0));
+        }
         check(mr_bvh_build(m_scene, 0));
     }
 
@@ -206,10 +260,24 @@ public:
             results[i].t = h[i].t;                        // minHit.t = tMax on a miss (BVH.cpp:444)
             if (!hit) continue;
             hits++;
+            if (h[i].prim & MR_PLANE_BIT) {                                         // Scene.cpp:223-229
+                const Plane *pl = static_cast<const Plane *>((*m_unbounded)[h[i].prim & ~MR_PLANE_BIT]);
+                results[i].P = rays[i].o + h[i].t * rays[i].d;                      // Plane.cpp:42
+                results[i].N = pl->normal();                                        // Plane.cpp:44
+                results[i].object = pl;
+                results[i].material = pl->getMaterial();
+                continue;
+            }
             const Flat &f = m_flat[h[i].prim];
-            const float beta = h[i].beta, gamma = h[i].gamma;
-            results[i].P = f.A + beta * f.BmA + gamma * f.CmA;                      // Triangle.cpp:160
-            results[i].N = (1 - beta - gamma) * f.nA + beta * f.nB + gamma * f.nC;  // Triangle.cpp:162
+            if (f.sphere) {
+                results[i].P = rays[i].o + h[i].t * rays[i].d;                      // Sphere.cpp:61
+                results[i].N = (results[i].P - f.A);                                // Sphere.cpp:62-63
+                results[i].N.normalize();
+            } else {
+                const float beta = h[i].beta, gamma = h[i].gamma;
+                results[i].P = f.A + beta * f.BmA + gamma * f.CmA;                      // Triangle.cpp:160
+                results[i].N = (1 - beta - gamma) * f.nA + beta * f.nB + gamma * f.nC;  // Triangle.cpp:162
+            }
             results[i].object = (*m_objs)[h[i].prim];                               // BVH.cpp:506
             results[i].material = results[i].object->getMaterial();                 // Triangle.cpp:166
         }
@@ -221,9 +289,9 @@ public:
 private:
     BVH(const BVH &);
     BVH &operator=(const BVH &);
-    struct Flat { Vector3 A, BmA, CmA, nA, nB, nC; };
+    struct Flat { bool sphere; Vector3 A, BmA, CmA, nA, nB, nC; };       // sphere: A = centre
     mr_scene *m_scene;
-    Objects *m_objs;
+    Objects *m_objs, *m_unbounded;
     std::vector<Flat> m_flat;
     int m_device;
 };
@@ -233,11 +301,12 @@ class Scene {
 public:
     void addObject(Object *pObj) {                        // Scene.h:20-25
         if (pObj->isBounded()) m_objects.push_back(pObj);
-        else throw MiroHipError(MR_ERR_INVALID, "unbounded objects are not part of the device path");
+        else m_unboundedObjects.push_back(pObj);
     }
     const Objects *objects() const { return &m_objects; }
+    const Objects *unboundedObjects() const { return &m_unboundedObjects; }
     void setDevice(int device) { m_bvh.setDevice(device); }
-    void preCalc() { m_bvh.build(&m_objects); }           // Scene.cpp:50-84, the BVH part (:72)
+    void preCalc() { m_bvh.setUnbounded(&m_unboundedObjects); m_bvh.build(&m_objects); }   // Scene.cpp:50-84, the BVH part (:72)
 
     bool trace(HitInfo &minHit, const Ray &ray, float tMin = 0.0f, float tMax = MIRO_TMAX) const {   // Scene.cpp:214
         bool hit = false;
@@ -257,7 +326,7 @@ public:
     const BVH &bvh() const { return m_bvh; }
 
 private:
-    Objects m_objects;
+    Objects m_objects, m_unboundedObjects;
     BVH m_bvh;
 };
 

@@ -14,6 +14,7 @@ HIT_DTYPE = np.dtype([("t", "<f4"), ("prim", "<u4"), ("beta", "<f4"), ("gamma", 
 MISS = 0xFFFFFFFF
 
 MR_TRACE_CLOSEST = 0
+MR_PLANE_BIT = 0x80000000
 MR_TRACE_ANY = 1 << 0
 MR_RAYS_ON_DEVICE = 1 << 1
 MR_HITS_ON_DEVICE = 1 << 2
@@ -26,6 +27,7 @@ MR_OK, MR_ERR_INVALID, MR_ERR_IO, MR_ERR_NOMEM, MR_ERR_HIP, MR_ERR_STATE = 0, -1
 # every symbol include/miro_hip.h declares (tests check the library exports each one)
 EXPORTED_SYMBOLS = [
     "mr_scene_create", "mr_scene_destroy", "mr_scene_add_mesh", "mr_scene_add_obj", "mr_scene_add_triangle",
+    "mr_scene_add_sphere", "mr_scene_add_plane",
     "mr_bvh_build", "mr_scene_get_info", "mr_scene_get_mesh", "mr_scene_export_tree",
     "mr_trace", "mr_trace_indirect", "mr_trace_get_stats", "mr_gen_eye_rays", "mr_gen_shadow_rays", "mr_hit_attrs",
     "mr_shade_direct", "mr_tonemap",
@@ -122,7 +124,9 @@ def load_library(path=None):
     L.mr_gen_eye_rays.argtypes = [vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                   C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     L.mr_gen_shadow_rays.argtypes = [vp, vp, vp, C.c_uint64, f32p, vp, vp, vp, vp]
-    L.mr_hit_attrs.argtypes = [vp, vp, C.c_uint64, vp, vp, vp]
+    L.mr_hit_attrs.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, vp]
+    L.mr_scene_add_sphere.argtypes = [vp, f32p, C.c_float, u32p]
+    L.mr_scene_add_plane.argtypes = [vp, f32p, f32p, C.c_uint32, u32p]
     L.mr_shade_direct.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, vp, C.POINTER(Light), f32p, C.c_uint32, vp, vp]
     L.mr_tonemap.argtypes = [vp, vp, C.c_uint64, vp, vp]
     L.mr_scene_set_materials.argtypes = [vp, C.POINTER(Material), C.c_uint32, u32p]
@@ -210,6 +214,21 @@ class Scene:
         _check(self.L.mr_scene_add_triangle(self.h, _f32p(v), _f32p(n)))
         return 1
 
+    def add_sphere(self, center, radius):
+        """Sphere as the next bounded object (Scene::addObject); returns its prim index."""
+        c = np.ascontiguousarray(center, dtype=np.float32).reshape(3)
+        prim = C.c_uint32(0)
+        _check(self.L.mr_scene_add_sphere(self.h, _f32p(c), float(radius), C.byref(prim)))
+        return prim.value
+
+    def add_plane(self, normal, origin, material=0):
+        """Plane as the next unbounded object; hits carry prim = MR_PLANE_BIT | index."""
+        n = np.ascontiguousarray(normal, dtype=np.float32).reshape(3)
+        o = np.ascontiguousarray(origin, dtype=np.float32).reshape(3)
+        idx = C.c_uint32(0)
+        _check(self.L.mr_scene_add_plane(self.h, _f32p(n), _f32p(o), int(material), C.byref(idx)))
+        return idx.value
+
     def add_arrays(self, v, n, vi, ni):
         v = np.ascontiguousarray(v, dtype=np.float32).reshape(-1, 3)
         n = np.ascontiguousarray(n, dtype=np.float32).reshape(-1, 3)
@@ -291,8 +310,9 @@ class Scene:
                                          _f32p(l), d_out.data_ptr(), d_src.data_ptr() if d_src is not None else None,
                                          d_count.data_ptr(), _stream_ptr(stream)))
 
-    def hit_attrs(self, d_hits, n, d_P, d_N, stream=None):
-        _check(self.L.mr_hit_attrs(self.h, d_hits.data_ptr(), n, d_P.data_ptr() if d_P is not None else None,
+    def hit_attrs(self, d_hits, n, d_P, d_N, stream=None, d_rays=None):
+        _check(self.L.mr_hit_attrs(self.h, d_rays.data_ptr() if d_rays is not None else None, d_hits.data_ptr(), n,
+                                   d_P.data_ptr() if d_P is not None else None,
                                    d_N.data_ptr() if d_N is not None else None, _stream_ptr(stream)))
 
     def shade_direct(self, d_rays, d_hits, n, d_shadow_hits, d_shadow_src, d_shadow_count, light_pos, wattage,

@@ -49,6 +49,42 @@ SCENES = {
 }
 
 
+def _spiral_objects():
+    """makeSpiralScene (assignment1.cpp:31-72): 149 spheres on a spiral, the plane y = -2, one triangle.  Centres and
+    radii are evaluated in double and rounded to fp32 once (the reference's own float/double mix depends on which
+    cos/sin overload its headers select; both sides of every parity test are fed these same numbers)."""
+    objs = []
+    max_i, a = 150, np.float32(0.15)
+    pi = np.float32(3.1415926535897932384626433832795028841972)
+    for i in range(1, max_i):
+        t = np.float32(i) / np.float32(max_i)
+        theta = np.float32(np.float32(4) * pi * t)
+        r = np.float32(a * theta)
+        x, y = np.float32(r * np.cos(np.float64(theta))), np.float32(r * np.sin(np.float64(theta)))
+        z = np.float32(np.float32(2) * (np.float32(2) * pi * a - r))
+        objs.append(("sphere", (float(x), float(y), float(z)), float(np.float32(r / np.float32(10)))))
+    objs.append(("plane", (0.0, 1.0, 0.0), (0.0, -2.0, 0.0)))
+    n2 = np.asarray([0.1, 0.1, -1.0], np.float32)
+    n3 = np.asarray([-0.1, -0.2, -1.0], np.float32)
+    n2 = n2 * (np.float32(1) / np.sqrt((n2 * n2).sum(dtype=np.float32)))
+    n3 = n3 * (np.float32(1) / np.sqrt((n3 * n3).sum(dtype=np.float32)))
+    objs.append(("tri", (0, 0, 0, 0, 3, 0, 5, 5, 0), (0, 0, -1) + tuple(float(c) for c in n2) + tuple(float(c) for c in n3)))
+    return objs
+
+
+# scenes with spheres / planes (assignment1.cpp); `objects` are added in order after any models
+SCENES["spiral"] = dict(models=[], floor=None, objects=_spiral_objects(),
+                        eye=(0.0, 0.0, -5.0), lookat=(0.0, 0.0, 0.0), up=UP, fov=45.0, light=(-3.0, 15.0, -15.0),
+                        wattage=1000.0)
+# A1makeSphereScene (assignment1.cpp:383-433): the floor triangle, then a sphere whose centre is never set and
+# therefore is Vector3() = (0, 1, 2) (Vector3.h:26-27)
+SCENES["a1sphere"] = dict(models=[], floor=None,
+                          objects=[("tri", (0, -1.5, 10, 10, -1.5, -10, -10, -1.5, -10), (0, 1, 0) * 3),
+                                   ("sphere", (0.0, 1.0, 2.0), 1.5)],
+                          eye=(-2.0, 1.0, 5.0), lookat=(0.0, 0.0, 0.0), up=UP, fov=45.0, light=(-3.0, 15.0, 3.0),
+                          wattage=500.0)
+
+
 def sponza_label():
     p = os.environ.get("MIRO_SPONZA_OBJ", "")
     return "sponza" if p and os.path.exists(p) else "sponza-standin"
@@ -80,6 +116,14 @@ def populate(scene, desc, cache_dir=None):
     if desc.get("floor") is not None:
         f = np.asarray(desc["floor"], np.float32).reshape(9)
         scene.add_triangle(f, np.asarray([0, 1, 0] * 3, np.float32))
+        n += 1
+    for obj in desc.get("objects", ()):
+        if obj[0] == "sphere":
+            scene.add_sphere(obj[1], obj[2])
+        elif obj[0] == "plane":
+            scene.add_plane(obj[1], obj[2])
+        else:
+            scene.add_triangle(np.asarray(obj[1], np.float32), np.asarray(obj[2], np.float32))
         n += 1
     return n
 

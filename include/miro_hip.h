@@ -45,6 +45,10 @@ typedef struct mr_ray { float ox, oy, oz, tmin, dx, dy, dz, tmax; } mr_ray;
  * P, N, material, object are rebuilt by the shim (Triangle.cpp:160-166). 16 bytes. */
 typedef struct mr_hit { float t; uint32_t prim; float beta, gamma; } mr_hit;
 #define MR_MISS 0xFFFFFFFFu
+/* A hit on an unbounded object (a Plane, kept in Scene::m_unboundedObjects, Scene.h:22-23) reports
+ * prim = MR_PLANE_BIT | its index in that list; spheres are bounded objects and use ordinary indices.
+ * beta = gamma = 0 for both; P = o + t*d (Sphere.cpp:61, Plane.cpp:42). */
+#define MR_PLANE_BIT 0x80000000u
 
 /* Indexed triangle mesh as TriangleMesh stores it (TriangleMesh.h:27-67). */
 typedef struct mr_mesh_desc {
@@ -105,6 +109,14 @@ mr_status mr_scene_add_mesh(mr_scene *scene, const mr_mesh_desc *mesh);
 mr_status mr_scene_add_obj(mr_scene *scene, const char *path, const float *ctm16, uint32_t *n_triangles_out);
 /* TriangleMesh::createSingleTriangle + setV1..3/setN1..3 (TriangleMeshLoad.cpp:15-56) */
 mr_status mr_scene_add_triangle(mr_scene *scene, const float v[9], const float n[9]);
+/* Sphere + setCenter/setRadius + Scene::addObject (Sphere.h:13-21, Sphere.cpp:28-69): the next bounded object;
+ * *prim_out (may be NULL) receives its object index, which mr_hit.prim and prim_material use. */
+mr_status mr_scene_add_sphere(mr_scene *scene, const float center[3], float radius, uint32_t *prim_out);
+/* Plane + setNormal/setOrigin + Scene::addObject (Plane.h:22-27, Plane.cpp:33-48): the next unbounded object,
+ * scanned after the BVH by every trace (Scene.cpp:220-230).  `material` indexes mr_scene_set_materials' table;
+ * *index_out (may be NULL) receives the plane's index. */
+mr_status mr_scene_add_plane(mr_scene *scene, const float normal[3], const float origin[3], uint32_t material,
+                             uint32_t *index_out);
 
 /* ---- BVH::build (BVH.cpp:60-339) via Scene::preCalc (Scene.cpp:50-84); uploads the scene ------- */
 mr_status mr_bvh_build(mr_scene *scene, const mr_build_opts *opts);
@@ -142,8 +154,11 @@ mr_status mr_gen_eye_rays(mr_scene *scene, const mr_camera *cam, uint32_t W, uin
 mr_status mr_gen_shadow_rays(mr_scene *scene, const mr_ray *d_rays, const mr_hit *d_hits, uint64_t n,
                              const float light[3], mr_ray *d_out, uint32_t *d_src, uint64_t *d_count,
                              void *stream);
-/* HitInfo::P and ::N (Triangle.cpp:160,162), device buffers of 3 floats per ray (either may be NULL) */
-mr_status mr_hit_attrs(mr_scene *scene, const mr_hit *d_hits, uint64_t n, float *d_P, float *d_N, void *stream);
+/* HitInfo::P and ::N as the object's intersect() leaves them (Triangle.cpp:160,162; Sphere.cpp:61-63;
+ * Plane.cpp:42-44), device buffers of 3 floats per ray (either may be NULL).  d_rays (the rays the hits belong
+ * to) may be NULL for scenes of triangles only. */
+mr_status mr_hit_attrs(mr_scene *scene, const mr_ray *d_rays, const mr_hit *d_hits, uint64_t n, float *d_P, float *d_N,
+                       void *stream);
 
 /* ---- Phong::shade for one point light over a traced frame ("next" row: the consumer of the shadow batch) --- */
 typedef struct mr_light {                             /* PointLight.h:8-59 */

@@ -35,6 +35,7 @@ void orc_scene_free(orc_scene *s)
     free(s->v); free(s->n); free(s->vi); free(s->ni);
     free(s->omin); free(s->omax); free(s->ocen);
     free(s->nodes); free(s->leaf_prims);
+    free(s->spheres); free(s->planes); free(s->plane_mat);
     orc_sse_free(s);
     free(s);
 }
@@ -78,6 +79,31 @@ int orc_scene_add_triangle(orc_scene *s, const float v[9], const float n[9])
 {
     static const uint32_t idx[3] = {0, 1, 2};
     return orc_scene_add_arrays(s, 3, v, 3, n, 1, idx, idx);
+}
+
+/* Sphere as a bounded object (Scene::addObject, Scene.h:20-25) */
+int orc_scene_add_sphere(orc_scene *s, const float center[3], float radius)
+{
+    scene_grow(s, 0, 0, 1);
+    s->spheres = (float *)realloc(s->spheres, sizeof(float) * 4 * (size_t)(s->nspheres + 1));
+    memcpy(s->spheres + 4 * (size_t)s->nspheres, center, sizeof(float) * 3);
+    s->spheres[4 * (size_t)s->nspheres + 3] = radius;
+    for (int k = 0; k < 3; k++) {
+        s->vi[3 * (size_t)s->nt + k] = k == 0 ? ORC_SPHERE_SLOT : (k == 1 ? (uint32_t)s->nspheres : 0u);
+        s->ni[3 * (size_t)s->nt + k] = s->vi[3 * (size_t)s->nt + k];
+    }
+    s->nspheres++;
+    return s->nt++;
+}
+
+int orc_scene_add_plane(orc_scene *s, const float normal[3], const float origin[3], uint32_t material)
+{
+    s->planes = (float *)realloc(s->planes, sizeof(float) * 6 * (size_t)(s->nplanes + 1));
+    s->plane_mat = (uint32_t *)realloc(s->plane_mat, sizeof(uint32_t) * (size_t)(s->nplanes + 1));
+    memcpy(s->planes + 6 * (size_t)s->nplanes, normal, sizeof(float) * 3);
+    memcpy(s->planes + 6 * (size_t)s->nplanes + 3, origin, sizeof(float) * 3);
+    s->plane_mat[s->nplanes] = material;
+    return s->nplanes++;
 }
 
 /* ------------------------------------------------------------------ Matrix4x4.h */
@@ -266,6 +292,12 @@ static void precalc_objects(orc_scene *s)
     s->ocen = (v3 *)malloc(sizeof(v3) * (size_t)(s->nt + 1));
     const v3 *V = (const v3 *)s->v;
     for (int i = 0; i < s->nt; i++) {
+        if (orc_is_sphere(s, (uint32_t)i)) {     /* Sphere.h:19-21: m_center -/+ Vector3(m_radius), m_center */
+            const float *sp = s->spheres + 4 * (size_t)s->vi[3*i+1];
+            v3 c = {sp[0], sp[1], sp[2]}, r = {sp[3], sp[3], sp[3]};
+            s->omin[i] = v3sub(c, r); s->omax[i] = v3add(c, r); s->ocen[i] = c;
+            continue;
+        }
         v3 a = V[s->vi[3*i]], b = V[s->vi[3*i+1]], c = V[s->vi[3*i+2]];
         v3 mn = a, mx = a;
         v3 vs[2] = {b, c};
@@ -439,7 +471,7 @@ int orc_scene_build(orc_scene *s, int leaf_size)
     build_rec(s, objs, s->nt, 0, c);                                  /* Scene.cpp:72 */
     free(objs);
     orc_sse_free(s);
-    if (leaf_size == 8) orc_sse_prepare(s);
+    if (leaf_size == 8 && s->nspheres == 0) orc_sse_prepare(s);   /* the packet restatement covers triangle leaves only */
     return s->n_nodes;
 }
 
@@ -483,6 +515,48 @@ int orc_tri_test(const orc_scene *s, uint32_t prim, const orc_ray *r, float tMin
     return 1;
 }
 
+/* Sphere::intersect (Sphere.cpp:28-69) */
+static int sphere_test(const orc_scene *s, uint32_t prim, const orc_ray *r, float tMin, float tMax, orc_hit *out)
+{
+    const float *sp = s->spheres + 4 * (size_t)s->vi[3 * (size_t)prim + 1];
+    v3 o = {r->ox, r->oy, r->oz}, d = {r->dx, r->dy, r->dz}, cen = {sp[0], sp[1], sp[2]};
+    const float radius = sp[3];
+    v3 toO = v3sub(o, cen);
+    const float a = v3dot(d, d);                                      /* ray.d.length2() */
+    const float b = v3dot(v3scale(d, 2), toO);                        /* dot(2*ray.d, toO) */
+    const float c = v3dot(toO, toO) - radius * radius;
+    const float discrim = b * b - 4.0f * a * c;
+    if (discrim < 0) return 0;
+    const float sqrt_discrim = sqrtf(discrim);
+    const float t[2] = {(-b - sqrt_discrim) / (2.0f * a), (-b + sqrt_discrim) / (2.0f * a)};
+    float tt;
+    if ((t[0] > tMin) && (t[0] < tMax)) tt = t[0];
+    else if ((t[1] > tMin) && (t[1] < tMax)) tt = t[1];
+    else return 0;
+    out->t = tt; out->beta = 0.0f; out->gamma = 0.0f; out->prim = prim;
+    return 1;
+}
+
+int orc_obj_test(const orc_scene *s, uint32_t prim, const orc_ray *r, float tMin, float tMax, orc_hit *out)
+{
+    if (orc_is_sphere(s, prim)) return sphere_test(s, prim, r, tMin, tMax, out);
+    return orc_tri_test(s, prim, r, tMin, tMax, out);
+}
+
+/* Plane::intersect (Plane.cpp:33-48); fabs() of a float compared with the double literal 1e-6 */
+static int plane_test(const orc_scene *s, int i, const orc_ray *r, float tMin, float tMax, orc_hit *out)
+{
+    const float *pl = s->planes + 6 * (size_t)i;
+    v3 n = {pl[0], pl[1], pl[2]}, org = {pl[3], pl[4], pl[5]};
+    v3 o = {r->ox, r->oy, r->oz}, d = {r->dx, r->dy, r->dz};
+    float ndotd = v3dot(n, d);
+    if ((double)fabsf(ndotd) < 1e-6) return 0;
+    float t = v3dot(n, v3sub(org, o)) / ndotd;
+    if (t < tMin || t > tMax) return 0;
+    out->t = t; out->beta = 0.0f; out->gamma = 0.0f; out->prim = ORC_PLANE_BIT | (uint32_t)i;
+    return 1;
+}
+
 /* slab test shared by BVH::intersect (BVH.cpp:447-458) and the scalar child test (:597-608) */
 static inline void slab(const float c[2][3], const orc_ray *r, float *minOverlap, float *maxOverlap)
 {
@@ -511,7 +585,7 @@ static int isect_children(const orc_scene *s, int node, const orc_ray *r, float 
         for (int i = 0; i < nd->b; i++) {                             /* :493-509 */
             uint32_t prim = s->leaf_prims[nd->a + i];
             ctr->tri_tests++;
-            if (orc_tri_test(s, prim, r, tMin, minHit->t, &tmp)) {
+            if (orc_obj_test(s, prim, r, tMin, minHit->t, &tmp)) {
                 if (tmp.t < minHit->t) { hit = 1; *minHit = tmp; }
             }
         }
@@ -541,8 +615,8 @@ static int isect_children(const orc_scene *s, int node, const orc_ray *r, float 
     return hit;
 }
 
-/* BVH::intersect (BVH.cpp:438-469) as called by Scene::trace (Scene.cpp:217); the
- * unbounded-object scan (:220-230) is empty for triangle scenes. */
+/* Scene::trace (Scene.cpp:214-231): BVH::intersect (BVH.cpp:438-469), then the unbounded-object scan (:220-230),
+ * each plane tested against the caller's tMin / tMax and kept when there was no hit yet or it is strictly nearer. */
 void orc_trace(const orc_scene *s, const orc_ray *rays, uint64_t n, orc_hit *hits, orc_counters *counters)
 {
     orc_counters ctr = {0, 0};
@@ -559,6 +633,10 @@ void orc_trace(const orc_scene *s, const orc_ray *rays, uint64_t n, orc_hit *hit
                 hit = isect_children(s, 0, r, r->tmin, r->tmax, &h, &ctr);
         }
         if (!hit) { h.t = r->tmax; h.prim = ORC_MISS; h.beta = 0; h.gamma = 0; }
+        for (int k = 0; k < s->nplanes; k++) {
+            orc_hit tmp;
+            if (plane_test(s, k, r, r->tmin, r->tmax, &tmp) && (!hit || tmp.t < h.t)) { hit = 1; h = tmp; }
+        }
         hits[i] = h;
     }
     if (counters) { counters->box_tests += ctr.box_tests; counters->tri_tests += ctr.tri_tests; }
@@ -569,9 +647,12 @@ void orc_trace_brute(const orc_scene *s, const orc_ray *rays, uint64_t n, orc_hi
     for (uint64_t i = 0; i < n; i++) {
         orc_hit best, tmp;
         best.t = rays[i].tmax; best.prim = ORC_MISS; best.beta = 0; best.gamma = 0;
+        int hit = 0;
         for (int p = 0; p < s->nt; p++)
-            if (orc_tri_test(s, (uint32_t)p, &rays[i], rays[i].tmin, best.t, &tmp))
-                if (tmp.t < best.t) best = tmp;
+            if (orc_obj_test(s, (uint32_t)p, &rays[i], rays[i].tmin, best.t, &tmp))
+                if (tmp.t < best.t) { best = tmp; hit = 1; }
+        for (int k = 0; k < s->nplanes; k++)
+            if (plane_test(s, k, &rays[i], rays[i].tmin, rays[i].tmax, &tmp) && (!hit || tmp.t < best.t)) { best = tmp; hit = 1; }
         hits[i] = best;
     }
 }
@@ -638,18 +719,39 @@ static inline void hit_point(const orc_scene *s, const orc_hit *h, v3 *P, int ss
         *P = v3add(v3add(A, v3scale(BmA, h->beta)), v3scale(CmA, h->gamma));
 }
 
+void orc_surface(const orc_scene *s, const orc_ray *ray, const orc_hit *h, v3 *P, v3 *N, int sse_order)
+{
+    const uint32_t p = h->prim;
+    if ((p & ORC_PLANE_BIT) || orc_is_sphere(s, p)) {
+        v3 o = {ray->ox, ray->oy, ray->oz}, d = {ray->dx, ray->dy, ray->dz};
+        *P = v3add(o, v3scale(d, h->t));                              /* ray.o + t*ray.d (Sphere.cpp:61, Plane.cpp:42) */
+        if (p & ORC_PLANE_BIT) {
+            const float *pl = s->planes + 6 * (size_t)(p & ~ORC_PLANE_BIT);
+            N->x = pl[0]; N->y = pl[1]; N->z = pl[2];                  /* Plane.cpp:44 */
+        } else {
+            const float *sp = s->spheres + 4 * (size_t)s->vi[3 * (size_t)p + 1];
+            v3 cen = {sp[0], sp[1], sp[2]};
+            *N = v3normalize(v3sub(*P, cen));                         /* Sphere.cpp:62-63 */
+        }
+        return;
+    }
+    hit_point(s, h, P, sse_order);
+    const v3 *Nn = (const v3 *)s->n;
+    v3 nA = Nn[s->ni[3*p]], nB = Nn[s->ni[3*p+1]], nC = Nn[s->ni[3*p+2]];
+    *N = v3add(v3add(v3scale(nA, 1 - h->beta - h->gamma), v3scale(nB, h->beta)), v3scale(nC, h->gamma));  /* Triangle.cpp:162 */
+}
+
 /* Phong::shade shadow ray (Phong.cpp:80-97) for a PointLight (PointLight.h:41-52) */
 uint64_t orc_shadow_rays(const orc_scene *s, const orc_ray *rays, const orc_hit *hits, uint64_t n,
                          const float light[3], orc_ray *out, uint64_t *src, int sse_order)
 {
     const float eps = 1e-4f;
-    (void)rays;
     uint64_t k = 0;
     v3 L = {light[0], light[1], light[2]};
     for (uint64_t i = 0; i < n; i++) {
         if (hits[i].prim == ORC_MISS) continue;
-        v3 P;
-        hit_point(s, &hits[i], &P, sse_order);
+        v3 P, Nunused;
+        orc_surface(s, rays ? &rays[i] : NULL, &hits[i], &P, &Nunused, sse_order);
         v3 l = v3sub(L, P);                                           /* getLightDirection */
         float falloff = v3dot(l, l);
         float len = sqrtf(falloff);
@@ -664,19 +766,17 @@ uint64_t orc_shadow_rays(const orc_scene *s, const orc_ray *rays, const orc_hit 
     return k;
 }
 
-void orc_hit_attrs(const orc_scene *s, const orc_hit *hits, uint64_t n, float *Pout, float *Nout)
+void orc_hit_attrs_rays(const orc_scene *s, const orc_ray *rays, const orc_hit *hits, uint64_t n, float *Pout, float *Nout)
 {
-    const v3 *Nn = (const v3 *)s->n;
     for (uint64_t i = 0; i < n; i++) {
         v3 P = {0, 0, 0}, N = {0, 1, 0};                              /* HitInfo defaults Ray.h:31-34 */
-        if (hits[i].prim != ORC_MISS) {
-            uint32_t p = hits[i].prim;
-            float beta = hits[i].beta, gamma = hits[i].gamma;
-            hit_point(s, &hits[i], &P, 0);
-            v3 nA = Nn[s->ni[3*p]], nB = Nn[s->ni[3*p+1]], nC = Nn[s->ni[3*p+2]];
-            N = v3add(v3add(v3scale(nA, 1 - beta - gamma), v3scale(nB, beta)), v3scale(nC, gamma));  /* :162 */
-        }
+        if (hits[i].prim != ORC_MISS) orc_surface(s, rays ? &rays[i] : NULL, &hits[i], &P, &N, 0);
         if (Pout) { Pout[3*i] = P.x; Pout[3*i+1] = P.y; Pout[3*i+2] = P.z; }
         if (Nout) { Nout[3*i] = N.x; Nout[3*i+1] = N.y; Nout[3*i+2] = N.z; }
     }
+}
+
+void orc_hit_attrs(const orc_scene *s, const orc_hit *hits, uint64_t n, float *Pout, float *Nout)
+{
+    orc_hit_attrs_rays(s, NULL, hits, n, Pout, Nout);
 }

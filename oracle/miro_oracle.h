@@ -17,6 +17,7 @@
  *   shadow rays           Phong.cpp:80-97, PointLight.h:41-52
  *   hit point / normal    Triangle.cpp:160-162, Scene.cpp:238-263
  *   STATS counters        BVH.cpp:64,88,461,496,632,643
+ *   spheres / planes      Sphere.cpp:28-69, Sphere.h:19-21, Plane.cpp:33-48, Scene.cpp:220-230, Scene.h:20-25
  *
  * Parity pin: the reference cannot be compiled in this image (every translation unit
  * reaches <GL/glut.h> through Miro.h:26 -> OpenGL.h:10, and GLUT is not installed), and it
@@ -54,6 +55,12 @@ int orc_scene_add_triangle(orc_scene *, const float v[9], const float n[9]);
 /* Append an indexed mesh given as flat arrays (synthetic scenes). */
 int orc_scene_add_arrays(orc_scene *, int nv, const float *v, int nn, const float *n,
                          int nt, const uint32_t *vi, const uint32_t *ni);
+
+/* Sphere (Sphere.h:13-20) as the next bounded object; returns its object (prim) index. */
+int orc_scene_add_sphere(orc_scene *, const float center[3], float radius);
+/* Plane (Plane.h:22-23) as the next unbounded object; hits report prim = ORC_PLANE_BIT | index.  Returns index. */
+int orc_scene_add_plane(orc_scene *, const float normal[3], const float origin[3], uint32_t material);
+#define ORC_PLANE_BIT 0x80000000u
 
 int orc_scene_counts(const orc_scene *, int *nv, int *nn, int *nt);
 const float    *orc_scene_vertices(const orc_scene *);
@@ -95,6 +102,9 @@ uint64_t orc_shadow_rays(const orc_scene *, const orc_ray *rays, const orc_hit *
 
 /* HitInfo reconstruction: P (Triangle.cpp:160), N un-normalised (Triangle.cpp:162). */
 void orc_hit_attrs(const orc_scene *, const orc_hit *hits, uint64_t n, float *P, float *N);
+
+/* same for scenes with spheres / planes, whose P = o + t*d needs the ray (Sphere.cpp:61-63, Plane.cpp:42-45) */
+void orc_hit_attrs_rays(const orc_scene *, const orc_ray *rays, const orc_hit *hits, uint64_t n, float *P, float *N);
 
 /* Phong::shade for one point light + per-pixel sample average; occluded[i] = shadow ray of primary ray i
  * hit something.  rgb: (n/spp)*3 linear floats.  (miro_oracle_shade.c) */

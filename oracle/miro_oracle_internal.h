@@ -3,6 +3,7 @@
 #ifndef MIRO_ORACLE_INTERNAL_H
 #define MIRO_ORACLE_INTERNAL_H
 
+#include <stddef.h>
 #include "miro_oracle.h"
 
 typedef struct { float x, y, z; } v3;
@@ -36,7 +37,23 @@ struct orc_scene {
     uint32_t *leaf_prims;
     int n_leaf_prims;
     void *sse;               /* packet cache of the SSE path */
+    /* non-triangle objects.  A sphere is a bounded object like any triangle (Scene.h:20-25): it takes the next
+     * object index, and its slot in vi/ni holds {ORC_SPHERE_SLOT, sphere index, 0}.  Planes are unbounded: they
+     * live in Scene::m_unboundedObjects and are scanned after the BVH (Scene.cpp:220-230). */
+    int nspheres, nplanes;
+    float *spheres;          /* cx, cy, cz, radius */
+    float *planes;           /* normal xyz, origin xyz */
+    uint32_t *plane_mat;     /* material id of each plane (for orc_trace_scene) */
 };
+
+#define ORC_SPHERE_SLOT 0xFFFFFFFFu
+static inline int orc_is_sphere(const orc_scene *s, uint32_t prim) { return s->nspheres && s->vi[3 * (size_t)prim] == ORC_SPHERE_SLOT; }
+
+/* the object test of a leaf (Object::intersect): Triangle::intersect or Sphere::intersect */
+int  orc_obj_test(const orc_scene *s, uint32_t prim, const orc_ray *r, float tMin, float tMax, orc_hit *out);
+/* HitInfo::P and HitInfo::N exactly as the object's intersect() leaves them (N of a triangle un-normalised,
+ * N of a sphere normalised, N of a plane as set); ray may be NULL for triangle hits */
+void orc_surface(const orc_scene *s, const orc_ray *ray, const orc_hit *h, v3 *P, v3 *N, int sse_order);
 
 int  orc_tri_test(const orc_scene *s, uint32_t prim, const orc_ray *r, float tMin, float tMax, orc_hit *out);
 void orc_sse_prepare(orc_scene *s);

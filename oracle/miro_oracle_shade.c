@@ -18,7 +18,6 @@ void orc_shade_direct(const orc_scene *s, const orc_ray *rays, const orc_hit *hi
                       float wattage, const float diffuse[3], int spp, float *rgb)
 {
     const float PI = 3.1415926535897932384626433832795028841972f;
-    const v3 *V = (const v3 *)s->v, *Nn = (const v3 *)s->n;
     v3 L = {light[0], light[1], light[2]};
     uint64_t npix = n / (uint64_t)spp;
     for (uint64_t pix = 0; pix < npix; pix++) {
@@ -27,13 +26,8 @@ void orc_shade_direct(const orc_scene *s, const orc_ray *rays, const orc_hit *hi
             uint64_t k = pix * (uint64_t)spp + (uint64_t)sm;
             float c[3] = {0, 0, 0};                                 /* miss: m_bgColor = 0 */
             if (hits[k].prim != ORC_MISS && !occluded[k]) {
-                uint32_t p = hits[k].prim;
-                float beta = hits[k].beta, gamma = hits[k].gamma;
-                v3 A = V[s->vi[3*p]], B = V[s->vi[3*p+1]], C = V[s->vi[3*p+2]];
-                v3 BmA = v3sub(B, A), CmA = v3sub(C, A);
-                v3 P = v3add(v3add(A, v3scale(BmA, beta)), v3scale(CmA, gamma));
-                v3 nA = Nn[s->ni[3*p]], nB = Nn[s->ni[3*p+1]], nC = Nn[s->ni[3*p+2]];
-                v3 N = v3add(v3add(v3scale(nA, 1 - beta - gamma), v3scale(nB, beta)), v3scale(nC, gamma));
+                v3 P, N;
+                orc_surface(s, &rays[k], &hits[k], &P, &N, 0);
                 N = divs(N, sqrtf(v3dot(N, N)));                    /* Scene.cpp:262 */
                 v3 l = v3sub(L, P);
                 float falloff = v3dot(l, l);
@@ -89,7 +83,11 @@ typedef struct {
     uint64_t rays_traced;
 } ts_ctx;
 
-static inline const float *mat_of(const ts_ctx *c, uint32_t prim) { return c->mats + 11 * (size_t)c->prim_mat[prim]; }
+static inline const float *mat_of(const ts_ctx *c, uint32_t prim)
+{
+    if (prim & ORC_PLANE_BIT) return c->mats + 11 * (size_t)c->s->plane_mat[prim & ~ORC_PLANE_BIT];
+    return c->mats + 11 * (size_t)c->prim_mat[prim];
+}
 static inline int any_pos(const float *v) { return v[0] > 0.f || v[1] > 0.f || v[2] > 0.f; }
 
 /* Scene::trace: closest hit + normalised N (Scene.cpp:262) */
@@ -100,7 +98,7 @@ static int scene_trace(ts_ctx *c, v3 o, v3 d, float tmin, float tmax, orc_hit *h
     c->rays_traced++;
     if (h->prim == ORC_MISS) return 0;
     float Pf[3], Nf[3];
-    orc_hit_attrs(c->s, h, 1, Pf, Nf);
+    orc_hit_attrs_rays(c->s, &r, h, 1, Pf, Nf);
     v3 n = {Nf[0], Nf[1], Nf[2]};
     *N = divs(n, sqrtf(v3dot(n, n)));
     P->x = Pf[0]; P->y = Pf[1]; P->z = Pf[2];

@@ -65,6 +65,9 @@ def lib():
         L.orc_shadow_rays.argtypes = [vp, vp, vp, C.c_uint64, f32p, vp, u64p, C.c_int]
         L.orc_shadow_rays.restype = C.c_uint64
         L.orc_hit_attrs.argtypes = [vp, vp, C.c_uint64, f32p, f32p]
+        L.orc_hit_attrs_rays.argtypes = [vp, vp, vp, C.c_uint64, f32p, f32p]
+        L.orc_scene_add_sphere.argtypes = [vp, f32p, C.c_float]
+        L.orc_scene_add_plane.argtypes = [vp, f32p, f32p, C.c_uint32]
         L.orc_shade_direct.argtypes = [vp, vp, vp, C.c_uint64, vp, f32p, f32p, C.c_float, f32p, C.c_int, f32p]
         L.orc_tonemap.argtypes = [f32p, C.c_uint64, vp]
         L.orc_trace_scene.argtypes = [vp, f32p, u32p, vp, C.c_uint64, f32p, f32p, C.c_float, C.c_int, f32p]
@@ -138,6 +141,17 @@ class Scene:
         vi = np.ascontiguousarray(vi, dtype=np.uint32).reshape(-1, 3)
         ni = np.ascontiguousarray(ni, dtype=np.uint32).reshape(-1, 3)
         return self.L.orc_scene_add_arrays(self.h, len(v), _f32p(v), len(n), _f32p(n), len(vi), _u32p(vi), _u32p(ni))
+
+    def add_sphere(self, center, radius):
+        """Sphere as the next bounded object (Scene::addObject); returns its prim index."""
+        c = np.ascontiguousarray(center, dtype=np.float32).reshape(3)
+        return self.L.orc_scene_add_sphere(self.h, _f32p(c), float(radius))
+
+    def add_plane(self, normal, origin, material=0):
+        """Plane as the next unbounded object; hits carry prim = 0x80000000 | index."""
+        n = np.ascontiguousarray(normal, dtype=np.float32).reshape(3)
+        o = np.ascontiguousarray(origin, dtype=np.float32).reshape(3)
+        return self.L.orc_scene_add_plane(self.h, _f32p(n), _f32p(o), int(material))
 
     def counts(self):
         a, b, c = C.c_int(), C.c_int(), C.c_int()
@@ -227,11 +241,16 @@ class Scene:
                                        wattage, depth, _f32p(rgb))
         return rgb, calls
 
-    def hit_attrs(self, hits):
+    def hit_attrs(self, hits, rays=None):
+        """HitInfo::P / ::N; `rays` is needed when the scene holds spheres or planes (P = o + t*d)."""
         hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
         P = np.empty((len(hits), 3), np.float32)
         N = np.empty((len(hits), 3), np.float32)
-        self.L.orc_hit_attrs(self.h, hits.ctypes.data, len(hits), _f32p(P), _f32p(N))
+        if rays is None:
+            self.L.orc_hit_attrs(self.h, hits.ctypes.data, len(hits), _f32p(P), _f32p(N))
+        else:
+            rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+            self.L.orc_hit_attrs_rays(self.h, rays.ctypes.data, hits.ctypes.data, len(hits), _f32p(P), _f32p(N))
         return P, N
 
 

@@ -56,3 +56,43 @@ def test_shim_hitinfo_matches_oracle(tmp_path, oracle, miro):
     ln = np.sqrt((N[:, 0] * N[:, 0] + N[:, 1] * N[:, 1]) + N[:, 2] * N[:, 2]).astype(np.float32)
     Nn = N * (np.float32(1) / ln)[:, None]                                                     # Scene.cpp:262
     assert np.array_equal(rec["f"][hit, 5:8].view(np.uint32), Nn[hit].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_shim_spheres_and_planes(tmp_path, oracle, miro):
+    """makeSpiralScene written against the shim's Sphere / Plane / Triangle classes (assignment1.cpp:31-72): HitInfo
+    of every kind of object equals the oracle's, planes come back as the unbounded object they are."""
+    exe = build_shim_test(tmp_path, miro)
+    d = scenes.SCENES["spiral"]
+    a = oracle_scene(oracle, "spiral")
+    rays = oracle.eye_rays(camera_of(oracle, "spiral"), 128, 96)
+    rays_path, out_path, obj_path = str(tmp_path / "rays.bin"), str(tmp_path / "out.bin"), str(tmp_path / "objs.txt")
+    rays.tofile(rays_path)
+    hexf = lambda x: float(np.float32(x)).hex()
+    with open(obj_path, "w") as fh:
+        for o in d["objects"]:
+            if o[0] == "sphere":
+                fh.write("s %s %s\n" % (" ".join(hexf(c) for c in o[1]), hexf(o[2])))
+            elif o[0] == "plane":
+                fh.write("p %s %s\n" % (" ".join(hexf(c) for c in o[1]), " ".join(hexf(c) for c in o[2])))
+            else:
+                fh.write("t %s %s\n" % (" ".join(hexf(c) for c in o[1]), " ".join(hexf(c) for c in o[2])))
+    r = subprocess.run([exe, "@" + obj_path, "-", rays_path, out_path, "100"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    rec = np.fromfile(out_path, dtype=np.dtype([("f", "<f4", 8), ("m", "<i4", 2)]))
+    want = a.trace(rays)
+    hit = want["prim"] != oracle.MISS
+    plane = hit & ((want["prim"] & 0x80000000) != 0)
+    bounded = hit & ~plane
+    assert plane.any() and bounded.any()
+    assert np.array_equal(rec["f"][:, 0] == 1.0, hit)
+    assert np.array_equal(rec["f"][:, 1].view(np.uint32), want["t"].view(np.uint32))
+    assert np.array_equal(rec["m"][bounded, 0], want["prim"][bounded].astype(np.int32))
+    assert np.array_equal(rec["m"][plane, 0], -2 - (want["prim"][plane] & 0x7FFFFFFF).astype(np.int32))
+    n_sph = sum(1 for o in d["objects"] if o[0] == "sphere")
+    assert (rec["m"][bounded, 1] == np.where(want["prim"][bounded] < n_sph, 8, 7)).all() and (rec["m"][plane, 1] == 9).all()
+    P, N = a.hit_attrs(want, rays)
+    assert np.array_equal(rec["f"][hit, 2:5].view(np.uint32), P[hit].view(np.uint32))
+    ln = np.sqrt((N[:, 0] * N[:, 0] + N[:, 1] * N[:, 1]) + N[:, 2] * N[:, 2]).astype(np.float32)
+    Nn = N * (np.float32(1) / ln)[:, None]                                                     # Scene.cpp:262
+    assert np.array_equal(rec["f"][hit, 5:8].view(np.uint32), Nn[hit].view(np.uint32))
