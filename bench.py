@@ -153,29 +153,36 @@ def main():
     (Vp, Tp), (Vs, Ts), _ = reference_counts(scene, (desc, W, H, bands, 168), desc["light"])
     Bp, Bs = algorithmic_bytes_per_ray(Vp, Tp), algorithmic_bytes_per_ray(Vs, Ts)
 
-    fr = mframe.FrameRenderer(scene, desc, W, H, spp=spp, bands=bands, jitter=spp > 1, seed=168, flags=flags)
+    # multi-GPU: the shard is shaded straight into the gather's send buffer; the gather of frame k is asynchronous and
+    # is waited for only when frame k+1 is about to overwrite that buffer, so it overlaps k+1's trace launches
+    gather = mframe.FrameGather(H, W, a.band, rank, world, dev) if world > 1 else None
+    fr = mframe.FrameRenderer(scene, desc, W, H, spp=spp, bands=bands, jitter=spp > 1, seed=168, flags=flags,
+                              rgb=gather.local if gather is not None and len(bands) else None)
     fr.generate(stream)
     torch.cuda.synchronize()
 
     def one_step(events=None):
-        if events is not None:
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            e[0].record(stream)
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if events is not None else None
+        if fr.n:
+            if e: e[0].record(stream)
             fr.trace_primary(stream)
-            e[1].record(stream)
+            if e: e[1].record(stream)
             fr.make_shadow_rays(stream)
-            e[2].record(stream)
+            if e: e[2].record(stream)
             fr.trace_shadow(stream, a.any_shadow)
-            e[3].record(stream)
+            if e: e[3].record(stream)
+        if gather is not None:
+            gather.wait()               # frame k-1 has left the send buffer (and, on rank 0, is de-interleaved)
+        if fr.n:
             fr.shade(stream)
-            events.append(e)
-        else:
-            fr.step(stream, a.any_shadow)
-        if world > 1:
-            mframe.gather_framebuffer(fr.d_rgb, H, W, a.band, rank, world)
+            if e: events.append(e)
+        if gather is not None:
+            gather.start()
 
     for _ in range(a.warmup):
         one_step()
+    if gather is not None:
+        gather.wait()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -184,6 +191,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         one_step(events)
+    if gather is not None:
+        gather.wait()                   # the last frame's gather and de-interleave belong to the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

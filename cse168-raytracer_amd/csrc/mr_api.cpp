@@ -154,7 +154,7 @@ mr_status flatten_and_upload(mr_scene *s) {
     d.root_ref = ref_of(0);
     d.n_inner = n_inner;
     d.n_tris = nt;
-    d.stack_depth = t.max_depth + 2;   // pending far children (<= one per level) + the kDone sentinel
+    d.stack_depth = t.max_depth + 1;   // pending far children (one per inner node on a root-to-leaf path, <= max_depth) + the kDone sentinel
     MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&s->d_stats), 2 * sizeof(unsigned long long)));
     MR_HIP_CHECK(hipMemset(s->d_stats, 0, 2 * sizeof(unsigned long long)));
     MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&s->d_work_counters), kWorkCounters * sizeof(unsigned long long)));

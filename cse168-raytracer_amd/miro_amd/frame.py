@@ -28,42 +28,86 @@ def rows_of(bands):
     return np.concatenate([np.arange(y0, y1, dtype=np.int64) for y0, y1 in bands])
 
 
+class FrameGather:
+    """The one collective of a frame, with everything that does not change from frame to
+    frame set up once: every rank owns a send buffer padded to the largest shard -- the renderer shades straight
+    into its leading rows (`local`), so there is no staging copy -- and rank `dst` owns the receive buffer, the
+    full frame and the row permutation that de-interleaves the bands.
+
+    `start()` enqueues the gather asynchronously (RCCL runs it on its own stream behind the shading kernel);
+    `wait()` makes the caller's stream wait for it and, on `dst`, de-interleaves.  A renderer calls `wait()` just
+    before it shades the next frame, so frame k's gather overlaps frame k+1's trace launches."""
+
+    def __init__(self, H, W, band, rank, world, device, dtype=torch.float32, group=None, dst=0):
+        self.H, self.W, self.band, self.rank, self.world, self.group, self.dst = H, W, band, rank, world, group, dst
+        self.counts = [sum(y1 - y0 for y0, y1 in band_rows(H, band, r, world)) for r in range(world)]
+        self.max_rows = max(self.counts)
+        self.send = torch.zeros((max(self.max_rows, 1) * W, 3), dtype=dtype, device=device)
+        self.local = self.send[:self.counts[rank] * W]            # [n_local_rows * W, 3], rows in band order
+        self.work = None
+        self.pending = False
+        self.full = None
+        if rank == dst:
+            self.recv = self.send.unsqueeze(0) if world == 1 else \
+                torch.empty((world, max(self.max_rows, 1) * W, 3), dtype=dtype, device=device)
+            self.full = torch.empty((H, W, 3), dtype=dtype, device=device)
+            dest = np.concatenate([rows_of(band_rows(H, band, r, world)) for r in range(world)])
+            src = np.concatenate([r * max(self.max_rows, 1) + np.arange(self.counts[r], dtype=np.int64) for r in range(world)])
+            self.dest_rows = torch.from_numpy(dest).to(device)
+            self.src_rows = torch.from_numpy(src).to(device)
+
+    def _staged(self):
+        import torch.distributed as dist
+        return self.world > 1 and self.send.is_cuda and dist.get_backend(self.group) == "gloo"
+
+    def start(self):
+        import torch.distributed as dist
+        if self.pending:
+            self.wait()
+        self.pending = True
+        if self.world == 1:
+            return
+        if self._staged():
+            # rehearsal of the multi-rank path on a box with fewer GPUs than ranks (MIRO_DIST_BACKEND=gloo): gloo has
+            # no CUDA gather, so the shard is staged through the host; the production path is the RCCL branch below
+            send_h = self.send.cpu()
+            recv_h = [torch.empty_like(send_h) for _ in range(self.world)] if self.rank == self.dst else None
+            dist.gather(send_h, recv_h, dst=self.dst, group=self.group)
+            if self.rank == self.dst:
+                self.recv.copy_(torch.stack(recv_h))
+            return
+        recv = list(self.recv.unbind(0)) if self.rank == self.dst else None
+        self.work = dist.gather(self.send, recv, dst=self.dst, group=self.group, async_op=True)
+
+    def wait(self):
+        """Returns the full [H, W, 3] frame on `dst` (valid for work enqueued after this call), None elsewhere."""
+        if not self.pending:
+            return self.full
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        self.pending = False
+        if self.rank != self.dst:
+            return None
+        rows = self.recv.reshape(-1, self.W * 3).index_select(0, self.src_rows)
+        self.full.view(self.H, self.W * 3).index_copy_(0, self.dest_rows, rows)
+        return self.full
+
+
 def gather_framebuffer(local_rgb, H, W, band, rank, world, group=None, dst=0):
-    """The one collective of a frame: every rank contributes the rows it rendered ([n_local_rows*W, 3] floats,
-    rows in band order); rank `dst` receives them in one gather and de-interleaves into [H, W, 3].
-    Contributions are padded to the largest shard so that a single fixed-size gather suffices."""
-    import torch.distributed as dist
-    counts = [sum(y1 - y0 for y0, y1 in band_rows(H, band, r, world)) for r in range(world)]
-    max_rows = max(counts)
-    send = torch.zeros((max_rows * W, 3), dtype=local_rgb.dtype, device=local_rgb.device)
-    send[:counts[rank] * W] = local_rgb.reshape(-1, 3)[:counts[rank] * W]
-    if world == 1:
-        recv = [send]
-    elif send.is_cuda and dist.get_backend(group) == "gloo":
-        # rehearsal of the multi-rank path on a box with fewer GPUs than ranks (MIRO_DIST_BACKEND=gloo): gloo has no
-        # CUDA gather, so the shard is staged through the host; the production path is the RCCL branch below
-        send_h = send.cpu()
-        recv_h = [torch.empty_like(send_h) for _ in range(world)] if rank == dst else None
-        dist.gather(send_h, recv_h, dst=dst, group=group)
-        recv = [t.to(send.device) for t in recv_h] if rank == dst else None
-    else:
-        recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-        dist.gather(send, recv, dst=dst, group=group)
-    if rank != dst:
-        return None
-    full = torch.empty((H, W, 3), dtype=local_rgb.dtype, device=local_rgb.device)
-    for r in range(world):
-        rows = torch.from_numpy(rows_of(band_rows(H, band, r, world))).to(full.device)
-        if len(rows):
-            full[rows] = recv[r][:counts[r] * W].reshape(counts[r], W, 3)
-    return full
+    """One-shot form of FrameGather: every rank contributes the rows it rendered ([n_local_rows*W, 3] floats, rows in
+    band order); rank `dst` receives them in one gather and de-interleaves into [H, W, 3]."""
+    g = FrameGather(H, W, band, rank, world, local_rgb.device, local_rgb.dtype, group, dst)
+    g.local.copy_(local_rgb.reshape(-1, 3)[:g.counts[rank] * W])
+    g.start()
+    return g.wait()
 
 
 # ------------------------------------------------------------------------------------------------ renderer
 class FrameRenderer:
     """All device buffers of one rank's share of a frame, resident for the lifetime of the object."""
 
-    def __init__(self, scene, desc, W, H, spp=1, bands=None, jitter=None, seed=168, flags=0, device=None):
+    def __init__(self, scene, desc, W, H, spp=1, bands=None, jitter=None, seed=168, flags=0, device=None, rgb=None):
         if isinstance(desc, str):
             desc = scenes.SCENES[desc]
         self.scene, self.desc, self.W, self.H, self.spp = scene, desc, W, H, spp
@@ -82,7 +126,8 @@ class FrameRenderer:
         self.d_shadow_hits = torch.empty((n, 4), **f32)
         self.d_src = torch.empty(n, dtype=torch.int32, device=self.device)
         self.d_count = torch.zeros(1, dtype=torch.int64, device=self.device)
-        self.d_rgb = torch.zeros((max(self.n_pixels, 1), 3), **f32)
+        # rgb: an external [n_pixels, 3] buffer to shade into (FrameGather.local on a multi-GPU node)
+        self.d_rgb = torch.zeros((max(self.n_pixels, 1), 3), **f32) if rgb is None else rgb
         self.cam = binding.make_camera(desc["eye"], desc["lookat"], desc["up"], desc["fov"])
 
     def bytes_resident(self):

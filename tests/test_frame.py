@@ -66,6 +66,42 @@ def test_gather_framebuffer_gloo_world2(tmp_path, H, W, band):
     assert torch.equal(full, want)
 
 
+def _pipelined_worker(rank, world, port, H, W, band, frames, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = mframe.FrameGather(H, W, band, rank, world, torch.device("cpu"))
+    rows = torch.from_numpy(mframe.rows_of(mframe.band_rows(H, band, rank, world)))
+    base = (rows[:, None] * W + torch.arange(W)[None, :]).to(torch.float32).reshape(-1, 1) * 4 + torch.arange(3, dtype=torch.float32)
+    got = []
+    for k in range(frames):
+        # the bench's step order: wait for frame k-1's gather, "shade" frame k into the send buffer, start its gather
+        prev = g.wait()
+        if rank == 0 and k > 0:
+            got.append(prev.clone())
+        g.local.copy_(base + 1000.0 * k)
+        g.start()
+    last = g.wait()
+    if rank == 0:
+        got.append(last.clone())
+        torch.save(torch.stack(got), out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_gather_pipelined_gloo_world2(tmp_path):
+    """FrameGather as bench.py drives it at N>1: asynchronous gather started after shading, waited for before the
+    next frame overwrites the send buffer; every frame arrives intact on rank 0."""
+    H, W, band, frames = 37, 5, 8, 4
+    out = str(tmp_path / "frames.pt")
+    mp.spawn(_pipelined_worker, args=(2, _free_port(), H, W, band, frames, out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    base = torch.arange(H * W, dtype=torch.float32).reshape(H, W, 1) * 4 + torch.arange(3, dtype=torch.float32)
+    assert got.shape[0] == frames
+    for k in range(frames):
+        assert torch.equal(got[k], base + 1000.0 * k)
+
+
 def test_gather_framebuffer_single_rank():
     H, W = 20, 7
     local = torch.arange(H * W * 3, dtype=torch.float32).reshape(-1, 3)
