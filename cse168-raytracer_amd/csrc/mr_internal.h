@@ -137,6 +137,11 @@ mr_status launch_shade(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit
                        const mr_hit *d_shadow_hits, const uint32_t *d_shadow_src, const unsigned long long *d_shadow_count,
                        uint8_t *d_occluded, const mr_light &light, const float diffuse[3], uint32_t spp, float *d_rgb,
                        hipStream_t stream);
+// final gather (Scene.cpp:285-299): queries of the diffuse hits (NaN normal elsewhere), then irradiance -> pixels
+mr_status launch_gather_queries(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits, unsigned long long n,
+                                float *d_pos, float *d_nrm, hipStream_t stream);
+mr_status launch_gather_accumulate(const float *d_irr_a, const float *d_irr_b, unsigned long long n, uint32_t spp,
+                                   float *d_rgb, hipStream_t stream);
 mr_status launch_tonemap(const float *d_rgb, unsigned long long n_values, uint8_t *d_out, hipStream_t stream);
 
 mr_status launch_shade_accumulate(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,

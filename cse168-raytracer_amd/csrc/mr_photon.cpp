@@ -262,4 +262,32 @@ mr_status mr_irradiance_estimate(mr_photon_map *m, const float *d_pos, const flo
                              static_cast<hipStream_t>(stream));
 }
 
+mr_status mr_final_gather(mr_scene *s, mr_photon_map *global_map, mr_photon_map *caustic_map, const mr_ray *d_rays,
+                          const mr_hit *d_hits, uint64_t n, float max_dist, uint32_t nphotons, uint32_t spp,
+                          float *d_scratch, float *d_rgb, void *stream_v) {
+    if (!s || !s->built || !s->on_device) return fail(MR_ERR_STATE, "scene is not resident on a device");
+    if (!d_rays || !d_hits || !d_scratch || !d_rgb) return fail(MR_ERR_INVALID, "NULL argument");
+    if (spp == 0 || n % spp != 0) return fail(MR_ERR_INVALID, "n (%llu) must be a multiple of spp (%u)", (unsigned long long)n, spp);
+    if (nphotons == 0 || nphotons > kKnnMaxK) return fail(MR_ERR_INVALID, "nphotons must be in [1, %d]", kKnnMaxK);
+    mr_photon_map *maps[2] = {global_map, caustic_map};
+    for (mr_photon_map *m : maps) {
+        if (!m) continue;
+        if (!m->balanced || !m->on_device) return fail(MR_ERR_STATE, "photon map is not balanced and resident on a device");
+        if (m->device != s->device) return fail(MR_ERR_INVALID, "photon map lives on device %d, the scene on %d", m->device, s->device);
+    }
+    if (n == 0) return MR_OK;
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    MR_HIP_CHECK(hipSetDevice(s->device));
+    float *d_pos = d_scratch, *d_nrm = d_scratch + 3 * n;
+    float *d_irr[2] = {d_scratch + 6 * n, d_scratch + 9 * n};
+    mr_status st = launch_gather_queries(s->dev, d_rays, d_hits, n, d_pos, d_nrm, stream);
+    if (st != MR_OK) return st;
+    for (int i = 0; i < 2; i++) {
+        if (!maps[i]) { d_irr[i] = nullptr; continue; }
+        st = launch_irradiance(maps[i]->dev, d_pos, d_nrm, n, max_dist, nphotons, d_irr[i], nullptr, nullptr, stream);
+        if (st != MR_OK) return st;
+    }
+    return launch_gather_accumulate(d_irr[0], d_irr[1], n, spp, d_rgb, stream);
+}
+
 }  // extern "C"

@@ -127,6 +127,14 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
     for (unsigned long long q = wave_id; q < nq; q += n_waves) {
         const float qx = qpos[3 * q], qy = qpos[3 * q + 1], qz = qpos[3 * q + 2];
         const float nx = qnrm[3 * q], ny = qnrm[3 * q + 1], nz = qnrm[3 * q + 2];
+        if (nx != nx) {                                       // NaN normal = "no query here" (mr_final_gather: miss / non-diffuse hit)
+            if (lane == 0) {
+                irrad[3 * q] = 0.0f; irrad[3 * q + 1] = 0.0f; irrad[3 * q + 2] = 0.0f;
+                if (found_out) found_out[q] = 0;
+                if (r2_out) r2_out[q] = 0.0f;
+            }
+            continue;
+        }
         const float md2 = max_dist * max_dist;
         float r2 = md2;                                       // np.dist2[0] (PhotonMap.cpp:99)
         int count = 0;

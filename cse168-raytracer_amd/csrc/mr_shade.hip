@@ -115,6 +115,48 @@ __global__ __launch_bounds__(kBlock) void shade_samples_kernel(ShadeArgs a, unsi
     }
 }
 
+// Queries of Scene::traceScene's photon-map term (Scene.cpp:285-292): hit point and the normalised normal of every
+// hit whose material is diffuse (Phong::isDiffuse, Phong.cpp:39-42); a NaN normal marks "no query".
+__global__ __launch_bounds__(kBlock) void gather_queries_kernel(SurfacePtrs m, const float *mats, const uint32_t *prim_mat,
+                                                                const mr_ray *rays, const mr_hit *hits, unsigned long long n,
+                                                                float *pos, float *nrm) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; k < n; k += stride) {
+        const float4 h = reinterpret_cast<const float4 *>(hits)[k];
+        const uint32_t prim = __float_as_uint(h.y);
+        float P[3] = {0.f, 0.f, 0.f}, N[3];
+        N[0] = N[1] = N[2] = __uint_as_float(0x7fc00000u);
+        if (prim != MR_MISS) {
+            const float *mt = mats + 11 * (size_t)material_id(m, prim_mat, prim);
+            if (mt[0] > 0.f || mt[1] > 0.f || mt[2] > 0.f) {
+                surface<true>(m, rays, k, h.x, prim, h.z, h.w, P, N);
+                const float inv = 1.0f / sqrtf((N[0] * N[0] + N[1] * N[1]) + N[2] * N[2]);   // Scene.cpp:262
+                N[0] *= inv; N[1] *= inv; N[2] *= inv;
+            }
+        }
+        for (int c = 0; c < 3; c++) { pos[3 * k + c] = P[c]; nrm[3 * k + c] = N[c]; }
+    }
+}
+
+// shadeResult += irradiance + caustic (Scene.cpp:298), averaged over the pixel's samples like the direct term
+__global__ __launch_bounds__(kBlock) void gather_accumulate_kernel(const float *irr_a, const float *irr_b, unsigned long long n_pixels,
+                                                                   uint32_t spp, float *rgb) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
+    const float inv = 1.0f / (float)spp;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < 3 * n_pixels; i += stride) {
+        const unsigned long long pix = i / 3, c = i % 3;
+        float acc = 0.0f;
+        for (uint32_t s = 0; s < spp; s++) {
+            const unsigned long long k = 3 * (pix * spp + s) + c;
+            float v = 0.0f;
+            if (irr_a) v = irr_a[k];
+            if (irr_b) v = irr_a ? v + irr_b[k] : irr_b[k];
+            acc += v;
+        }
+        rgb[i] += spp > 1 ? acc * inv : acc;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void tonemap_kernel(const float *rgb, unsigned long long n_values, uint8_t *out) {
     const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
     for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < n_values; i += stride) {
@@ -154,6 +196,24 @@ mr_status launch_shade(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit
         hipLaunchKernelGGL(shade_samples_kernel, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, n);
     else
         hipLaunchKernelGGL(shade_pixels_kernel, dim3(grid_for(a.n_pixels)), dim3(kBlock), 0, stream, a);
+    MR_HIP_CHECK(hipGetLastError());
+    return MR_OK;
+}
+
+mr_status launch_gather_queries(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits, unsigned long long n,
+                                float *d_pos, float *d_nrm, hipStream_t stream) {
+    if (n == 0) return MR_OK;
+    hipLaunchKernelGGL(gather_queries_kernel, dim3(grid_for(n)), dim3(kBlock), 0, stream, surface_ptrs(ds), ds.materials,
+                       ds.prim_material, d_rays, d_hits, n, d_pos, d_nrm);
+    MR_HIP_CHECK(hipGetLastError());
+    return MR_OK;
+}
+
+mr_status launch_gather_accumulate(const float *d_irr_a, const float *d_irr_b, unsigned long long n, uint32_t spp,
+                                   float *d_rgb, hipStream_t stream) {
+    if (n == 0 || (!d_irr_a && !d_irr_b)) return MR_OK;
+    hipLaunchKernelGGL(gather_accumulate_kernel, dim3(grid_for(3 * (n / spp))), dim3(kBlock), 0, stream, d_irr_a, d_irr_b,
+                       n / spp, spp, d_rgb);
     MR_HIP_CHECK(hipGetLastError());
     return MR_OK;
 }

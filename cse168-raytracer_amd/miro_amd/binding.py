@@ -34,6 +34,7 @@ EXPORTED_SYMBOLS = [
     "mr_scene_set_materials", "mr_shade_accumulate", "mr_gen_secondary_rays",
     "mr_photon_map_create", "mr_photon_map_destroy", "mr_photon_map_store", "mr_photon_map_scale",
     "mr_photon_map_balance", "mr_photon_map_count", "mr_photon_map_export", "mr_irradiance_estimate",
+    "mr_final_gather",
     "mr_last_error", "mr_version",
 ]
 
@@ -132,6 +133,7 @@ def load_library(path=None):
     L.mr_scene_set_materials.argtypes = [vp, C.POINTER(Material), C.c_uint32, u32p]
     L.mr_shade_accumulate.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, C.POINTER(Light), C.c_uint32, vp, vp]
     L.mr_gen_secondary_rays.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp, vp]
+    L.mr_final_gather.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_float, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.mr_photon_map_create.argtypes = [C.c_int32, C.c_uint32, C.POINTER(vp)]
     L.mr_photon_map_destroy.argtypes = [vp]
     L.mr_photon_map_store.argtypes = [vp, C.c_uint32, f32p, f32p, f32p]
@@ -325,6 +327,14 @@ class Scene:
         _check(self.L.mr_shade_direct(self.h, d_rays.data_ptr(), d_hits.data_ptr(), n, d_shadow_hits.data_ptr(),
                                       d_shadow_src.data_ptr(), d_shadow_count.data_ptr(), C.byref(lt), _f32p(df), spp,
                                       d_rgb.data_ptr(), _stream_ptr(stream)))
+
+    def final_gather(self, global_map, caustic_map, d_rays, d_hits, n, d_scratch, d_rgb, max_dist=1e10, nphotons=500,
+                     spp=1, stream=None):
+        """Scene.cpp:285-299: irradiance + caustic estimate at every diffuse hit, added to the pixels."""
+        _check(self.L.mr_final_gather(self.h, global_map.h if global_map is not None else None,
+                                      caustic_map.h if caustic_map is not None else None, d_rays.data_ptr(),
+                                      d_hits.data_ptr(), n, max_dist, nphotons, spp, d_scratch.data_ptr(), d_rgb.data_ptr(),
+                                      _stream_ptr(stream)))
 
     def set_materials(self, materials, prim_material=None):
         """materials: list of (diffuse, specular, transmission, shininess, refract_index) as Phong's constructor takes

@@ -158,6 +158,16 @@ class FrameRenderer:
         self.scene.shade_direct(self.d_rays, self.d_hits, self.n, self.d_shadow_hits, self.d_src, self.d_count,
                                 self.desc["light"], self.desc["wattage"], self.d_rgb, spp=self.spp, stream=stream)
 
+    def final_gather(self, global_map, caustic_map=None, nphotons=500, max_dist=1e10, stream=None):
+        """BASELINE config 5: the photon-map term of Scene::traceScene (Scene.cpp:285-299) for the primary hits of this
+        frame, added to d_rgb after `step()`.  The scratch (48 B per ray) is allocated on first use."""
+        if self.n == 0:
+            return
+        if getattr(self, "d_gather", None) is None:
+            self.d_gather = torch.empty(12 * self.n, dtype=torch.float32, device=self.device)
+        self.scene.final_gather(global_map, caustic_map, self.d_rays, self.d_hits, self.n, self.d_gather, self.d_rgb,
+                                max_dist=max_dist, nphotons=nphotons, spp=self.spp, stream=stream)
+
     def step(self, stream=None, any_hit=False):
         """One pass of the hot path over this rank's resident rays: primary batch, shadow batch, shade."""
         if self.n == 0:

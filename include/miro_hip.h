@@ -220,6 +220,14 @@ mr_status mr_irradiance_estimate(mr_photon_map *map, const float *d_pos, const f
                                  float max_dist, uint32_t nphotons, float *d_irrad, int32_t *d_found, float *d_r2,
                                  void *stream);
 
+/* The photon-map term of Scene::traceScene (Scene.cpp:285-299) for a traced batch: for every ray whose hit has a
+ * diffuse material (Phong::isDiffuse), irradiance_estimate on the global and on the caustic map (either may be NULL)
+ * at the hit point with the normalised normal, and (irradiance + caustic) averaged over the pixel's spp samples
+ * added to d_rgb[ray / spp].  d_scratch: 12 * n floats on the device (query positions, normals, two results). */
+mr_status mr_final_gather(mr_scene *scene, mr_photon_map *global_map, mr_photon_map *caustic_map, const mr_ray *d_rays,
+                          const mr_hit *d_hits, uint64_t n, float max_dist, uint32_t nphotons, uint32_t spp,
+                          float *d_scratch, float *d_rgb, void *stream);
+
 const char *mr_last_error(void);
 const char *mr_version(void);
 
