@@ -25,6 +25,10 @@ namespace mr {
 namespace {
 
 constexpr int kBlock = 256;          // 4 waves per workgroup
+#ifndef MIRO_TRACE_BLOCK
+#define MIRO_TRACE_BLOCK 256
+#endif
+constexpr int kTraceBlock = MIRO_TRACE_BLOCK;   // threads per workgroup of the trace kernels (their LDS stack is [depth][kTraceBlock])
 constexpr int kTraceGridCap = 32768; // workgroups per trace launch (see launch_trace_t)
 // Default 11 = min/max slabs on (corner - o) * (1/d) + while-while + wave-uniform nodes/leaves through the scalar
 // cache: bit-identical to variant 0 (the literal select form) on 3 scenes x (33 M primary + 33 M shadow + 16 M random rays), tools/ab_variants.py.  Variant 7 (lean fma
@@ -206,10 +210,10 @@ __device__ __forceinline__ bool object_test(const float4 q0, const float4 q1, co
 //            triangle loop.
 // ---------------------------------------------------------------------------------------------------
 // `cur` is the node the lane is at: >= 0 inner node, < 0 leaf reference, kDone = no more work.  `sp` is the BYTE
-// offset in LDS of the lane's next free stack slot (slots of one lane are kBlock * 4 bytes apart); the bottom slot
+// offset in LDS of the lane's next free stack slot (slots of one lane are kTraceBlock * 4 bytes apart); the bottom slot
 // of every lane holds kDone, so a pop needs no emptiness test: popping the sentinel ends the ray.
 constexpr int kDone = (int)0x80000000;
-constexpr int kStackStride = kBlock * (int)sizeof(int);
+constexpr int kStackStride = kTraceBlock * (int)sizeof(int);
 struct Lane {
     float best_t, best_b, best_g;
     int best_pos;
@@ -394,10 +398,10 @@ __device__ __forceinline__ void traverse(const TraceParams &p, const RayRegs &r,
 }
 
 template <bool EXACT, bool ANY, bool STATS, int VAR>
-__global__ __launch_bounds__(kBlock) void trace_kernel(TraceParams p) {
-    extern __shared__ int s_stack[];                  // [stack_depth][kBlock]
+__global__ __launch_bounds__(kTraceBlock) void trace_kernel(TraceParams p) {
+    extern __shared__ int s_stack[];                  // [stack_depth][kTraceBlock]
     const int tid = threadIdx.x;
-    const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
+    const unsigned long long stride = (unsigned long long)gridDim.x * kTraceBlock;
     Stats st = {0ull, 0ull};
     constexpr bool kMinMax = !STATS && (VAR & 1);
     constexpr bool kWW = (VAR & 2) != 0;
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(TraceParams p) {
     if (p.n_dev) { const unsigned long long nd = *p.n_dev; if (nd < n_rays) n_rays = nd; }
     const unsigned long long n_round = kWW ? ((n_rays + 63ull) & ~63ull) : n_rays;   // whole waves for __any
 
-    for (unsigned long long idx = (unsigned long long)blockIdx.x * kBlock + tid; idx < n_round; idx += stride) {
+    for (unsigned long long idx = (unsigned long long)blockIdx.x * kTraceBlock + tid; idx < n_round; idx += stride) {
         const bool live = idx < n_rays;
         // two dwordx4 loads per lane, 32-byte stride: every byte of the fetched lines is used
         float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(1.f, 1.f, 1.f, -1.f);
@@ -497,7 +501,7 @@ constexpr unsigned long long kPoolChunk = 1024;
 constexpr int kPersistentSafeSlab = 1;    // same slab arithmetic as the default kernel (bit-identical results)
 
 template <bool EXACT, bool ANY, int REFILL_MIN>
-__global__ __launch_bounds__(kBlock) void trace_persistent_kernel(TraceParams p, unsigned long long *next_ray) {
+__global__ __launch_bounds__(kTraceBlock) void trace_persistent_kernel(TraceParams p, unsigned long long *next_ray) {
     extern __shared__ int s_stack[];
     const int tid = threadIdx.x, lane = tid & 63;
     Stats st = {0ull, 0ull};
@@ -723,7 +727,7 @@ inline int trace_grid_cap() {
 
 template <bool EXACT, bool ANY, bool STATS, int VAR>
 mr_status launch_trace_t(const TraceParams &p, hipStream_t stream) {
-    const size_t lds = (size_t)p.stack_depth * kBlock * sizeof(int);
+    const size_t lds = (size_t)p.stack_depth * kTraceBlock * sizeof(int);
     if (lds > 160 * 1024) return fail(MR_ERR_INVALID, "traversal stack of depth %d does not fit in LDS", p.stack_depth);
     if (lds > 64 * 1024)
         MR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&trace_kernel<EXACT, ANY, STATS, VAR>),
@@ -731,11 +735,11 @@ mr_status launch_trace_t(const TraceParams &p, hipStream_t stream) {
     // Many short-lived workgroups balance better than a resident grid that strides over its rays: with exactly one
     // chip-full of workgroups (1792) the 33 M-ray frame runs 13 % slower than with the capped grid below, because the
     // hardware dispatcher rebalances at workgroup granularity while a static stride cannot.
-    unsigned long long blocks = (p.n + kBlock - 1) / kBlock;
+    unsigned long long blocks = (p.n + kTraceBlock - 1) / kTraceBlock;
     const unsigned long long cap = (unsigned long long)trace_grid_cap();
     if (blocks > cap) blocks = cap;
     const unsigned grid = blocks ? (unsigned)blocks : 1u;
-    hipLaunchKernelGGL((trace_kernel<EXACT, ANY, STATS, VAR>), dim3(grid), dim3(kBlock), lds, stream, p);
+    hipLaunchKernelGGL((trace_kernel<EXACT, ANY, STATS, VAR>), dim3(grid), dim3(kTraceBlock), lds, stream, p);
     MR_HIP_CHECK(hipGetLastError());
     return MR_OK;
 }
@@ -757,7 +761,7 @@ static int trace_variant() {
 
 template <bool EXACT, bool ANY, int REFILL_MIN>
 static mr_status launch_persistent(const TraceParams &p, hipStream_t stream) {
-    const size_t lds = (size_t)p.stack_depth * kBlock * sizeof(int);
+    const size_t lds = (size_t)p.stack_depth * kTraceBlock * sizeof(int);
     if (lds > 160 * 1024) return fail(MR_ERR_INVALID, "traversal stack of depth %d does not fit in LDS", p.stack_depth);
     auto kern = &trace_persistent_kernel<EXACT, ANY, REFILL_MIN>;
     if (lds > 64 * 1024)
@@ -765,13 +769,13 @@ static mr_status launch_persistent(const TraceParams &p, hipStream_t stream) {
     int dev = 0, cus = 256, per_cu = 1;
     MR_HIP_CHECK(hipGetDevice(&dev));
     MR_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    MR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), kBlock, lds));
+    MR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), kTraceBlock, lds));
     if (per_cu < 1) per_cu = 1;
-    unsigned long long want = (p.n + kBlock - 1) / kBlock;
+    unsigned long long want = (p.n + kTraceBlock - 1) / kTraceBlock;
     unsigned long long grid = (unsigned long long)cus * (unsigned)per_cu;
     if (want < grid) grid = want;
     MR_HIP_CHECK(hipMemsetAsync(p.work_counter, 0, sizeof(unsigned long long), stream));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds, stream, p, p.work_counter);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kTraceBlock), lds, stream, p, p.work_counter);
     MR_HIP_CHECK(hipGetLastError());
     return MR_OK;
 }

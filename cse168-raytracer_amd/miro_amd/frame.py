@@ -38,8 +38,10 @@ class FrameGather:
     `wait()` makes the caller's stream wait for it and, on `dst`, de-interleaves.  A renderer calls `wait()` just
     before it shades the next frame, so frame k's gather overlaps frame k+1's trace launches."""
 
-    def __init__(self, H, W, band, rank, world, device, dtype=torch.float32, group=None, dst=0):
+    def __init__(self, H, W, band, rank, world, device, dtype=torch.float32, group=None, dst=0, always_collective=False):
+        """always_collective: go through torch.distributed even when world == 1 (exercises the RCCL call on one GPU)"""
         self.H, self.W, self.band, self.rank, self.world, self.group, self.dst = H, W, band, rank, world, group, dst
+        self.local_only = world == 1 and not always_collective
         self.counts = [sum(y1 - y0 for y0, y1 in band_rows(H, band, r, world)) for r in range(world)]
         self.max_rows = max(self.counts)
         self.send = torch.zeros((max(self.max_rows, 1) * W, 3), dtype=dtype, device=device)
@@ -48,7 +50,7 @@ class FrameGather:
         self.pending = False
         self.full = None
         if rank == dst:
-            self.recv = self.send.unsqueeze(0) if world == 1 else \
+            self.recv = self.send.unsqueeze(0) if self.local_only else \
                 torch.empty((world, max(self.max_rows, 1) * W, 3), dtype=dtype, device=device)
             self.full = torch.empty((H, W, 3), dtype=dtype, device=device)
             dest = np.concatenate([rows_of(band_rows(H, band, r, world)) for r in range(world)])
@@ -58,14 +60,14 @@ class FrameGather:
 
     def _staged(self):
         import torch.distributed as dist
-        return self.world > 1 and self.send.is_cuda and dist.get_backend(self.group) == "gloo"
+        return not self.local_only and self.send.is_cuda and dist.get_backend(self.group) == "gloo"
 
     def start(self):
         import torch.distributed as dist
         if self.pending:
             self.wait()
         self.pending = True
-        if self.world == 1:
+        if self.local_only:
             return
         if self._staged():
             # rehearsal of the multi-rank path on a box with fewer GPUs than ranks (MIRO_DIST_BACKEND=gloo): gloo has

@@ -194,3 +194,29 @@ def test_tile_sharding_is_invisible_in_the_result(miro, world):
         part = mframe.gather_framebuffer(fr.d_rgb, H, W, band, 0, 1) if world == 1 else fr.d_rgb.reshape(len(rows), W, 3)
         full[rows] = part
     assert torch.equal(full.view(torch.int32), ref_rgb.view(torch.int32))
+
+
+@gpu
+def test_frame_gather_through_rccl_single_rank():
+    """The collective exactly as bench.py issues it at N>1 -- asynchronous dist.gather on the "nccl" (= RCCL) backend
+    into views of one receive buffer, stream-level wait, de-interleave on the device -- exercised with a one-rank
+    process group, which is all a one-GPU box can hold."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        H, W, band = 37, 5, 8
+        g = mframe.FrameGather(H, W, band, 0, 1, dev, always_collective=True)
+        base = (torch.arange(H * W, dtype=torch.float32, device=dev).reshape(-1, 1) * 4 + torch.arange(3, dtype=torch.float32, device=dev))
+        for k in range(3):
+            g.wait()
+            g.local.copy_(base + 1000.0 * k)
+            g.start()
+        full = g.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(full.reshape(-1, 3), base + 2000.0)
+    finally:
+        dist.destroy_process_group()
