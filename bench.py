@@ -75,7 +75,14 @@ def cpu_baseline(desc, label, W, H, spp, threads):
     t3 = time.perf_counter()
     n = len(rays) + len(sh)
     secs = (t1 - t0) + (t3 - t2)
+    # the same path on one thread (SURVEY.md section 8d asks for both), on every spp-th ray of the sample
+    r1, s1 = rays[::max(spp, 1)].copy(), sh[::max(spp, 1)].copy()
+    t4 = time.perf_counter()
+    s.trace_sse(r1, threads=1)
+    s.trace_sse(s1, threads=1)
+    t5 = time.perf_counter()
     return dict(value=round(n / secs / 1e6, 3), unit="Mrays/s", cores=int(used), kind="port",
+                single_thread_mrays_s=round((len(r1) + len(s1)) / (t5 - t4) / 1e6, 3),
                 sample="%s %dx%d %d spp: %d primary + %d shadow rays, SSE4.1 packet path (8 tris/leaf), OpenMP "
                        "dynamic chunks of 1024 rays, %.2f s wall" % (label, W, H, spp, len(rays), len(sh), secs))
 

@@ -25,8 +25,8 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
-constexpr int kCap = 1024;         // candidate slots per wave
-constexpr int kStack = 512;        // pending block roots per wave
+constexpr int kCap = 704;          // candidate slots per wave: kTighten + one block of 63 candidates + 1
+constexpr int kStack = 256;        // pending block roots per wave: <= 64 per block level, 4 block levels = 24 tree levels (checked at launch)
 constexpr int kTighten = 640;      // compress (tighten the radius) once this many candidates are buffered
 
 struct WaveLds {
@@ -157,25 +157,28 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
             const float qc = plane == 0 ? qx : (plane == 1 ? qy : qz);
             const float d1 = qc - pc;                         // :161
             const bool desc = valid && j < pm.half;           // :160
-            // reachability inside the block, level by level; `path` collects the far-side steps (most significant =
-            // nearest the block root), which is the order the reference's near-first recursion visits subtrees in;
-            // `lb` is the largest squared plane distance crossed on the far side (a lower bound of the distance)
-            bool reach = valid && lv == 0;
+            // Reachability inside the block.  A lane's node is reached iff every step from the block root down to it is
+            // allowed by the reference's rule (:163-172): the near side always, the far side only if the splitting
+            // plane is inside the radius.  Each lane walks its own ancestor chain: the ancestors' plane distances come
+            // from their lanes through independent __shfl's (no level-by-level dependency), their "descends" flag
+            // from the index alone.  `path` collects the far-side steps (most significant = nearest the block root),
+            // which is the order the reference's near-first recursion visits subtrees in; `lb` is the largest squared
+            // plane distance crossed on the far side (a lower bound of the distance to anything below).
+            bool reach = valid;
             int path = 0;
             float lb = lb_block;
-            for (int L = 1; L <= 5; L++) {
-                const int p_reach = __shfl((int)reach, parent_lane, 64);
-                const int p_desc = __shfl((int)desc, parent_lane, 64);
-                const float p_d1 = __shfl(d1, parent_lane, 64);
-                const int p_path = __shfl(path, parent_lane, 64);
-                const float p_lb = __shfl(lb, parent_lane, 64);
-                if (lv == L && valid) {
-                    const bool is_right = (j & 1) != 0, near_right = p_d1 > 0.0f;     // :163-172
+#pragma unroll
+            for (int s = 1; s <= 5; s++) {
+                const int anc_lane = ((lane + 1) >> s) - 1;                         // -1 (-> lane 63, unused) above the root
+                const float a_d1 = __shfl(d1, anc_lane & 63, 64);
+                if (s <= lv) {
+                    const long long anc = jj >> s;                                   // the ancestor's tree index
+                    const bool is_right = ((jj >> (s - 1)) & 1) != 0, near_right = a_d1 > 0.0f;
                     const bool far_step = is_right != near_right;
-                    const float pd2 = p_d1 * p_d1;
-                    reach = p_reach && p_desc && (!far_step || pd2 < r2);
-                    path = (p_path << 1) | (far_step ? 1 : 0);
-                    lb = far_step ? fmaxf(p_lb, pd2) : p_lb;
+                    const float pd2 = a_d1 * a_d1;
+                    reach = reach && anc < (long long)pm.half && (!far_step || pd2 < r2);
+                    path |= (far_step ? 1 : 0) << (s - 1);
+                    if (far_step) lb = fmaxf(lb, pd2);
                 }
             }
             // the photon itself (:177-186)
@@ -238,6 +241,9 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
 
 mr_status launch_irradiance(const PhotonMapDev &pm, const float *d_pos, const float *d_normal, unsigned long long nq,
                             float max_dist, uint32_t k, float *d_irrad, int32_t *d_found, float *d_r2, hipStream_t stream) {
+    static_assert(kTighten + 64 <= kCap && kKnnMaxK <= kTighten, "candidate buffer must hold k plus one block");
+    if (pm.n >= (1 << 24))
+        return fail(MR_ERR_INVALID, "photon maps of 2^24 photons or more need a deeper block stack (kStack)");
     unsigned long long blocks = (nq + kWaves - 1) / kWaves;
     if (blocks > 256ull * 16ull) blocks = 256ull * 16ull;
     hipLaunchKernelGGL(irradiance_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, pm, d_pos, d_normal, nq, max_dist,
