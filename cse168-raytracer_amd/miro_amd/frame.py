@@ -179,6 +179,23 @@ class FrameRenderer:
         self.trace_shadow(stream, any_hit)
         self.shade(stream)
 
+    def capture(self, any_hit=False):
+        """One frame step recorded into a HIP graph (torch.cuda.CUDAGraph): small frames are launch-bound -- five
+        kernels and a memset of tens of microseconds each -- and replay as one submission.  The step must have run
+        once before (the library's grow-only scratch buffers are sized outside the capture).  Returns the graph;
+        `graph.replay()` re-renders into d_rgb."""
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            self.step(side, any_hit)            # warm-up on the capture stream
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            self.step(torch.cuda.current_stream(self.device), any_hit)
+        return g
+
     def render_specular(self, depth=10, stream=None):
         """Scene::traceScene with reflective / refractive materials (Scene.cpp:270-346) as wavefront bounces: every
         level traces its queue, shades it (weight x Phong::shade added to the ray's pixel), and emits the reflect /

@@ -220,3 +220,22 @@ def test_frame_gather_through_rccl_single_rank():
         assert torch.equal(full.reshape(-1, 3), base + 2000.0)
     finally:
         dist.destroy_process_group()
+
+
+@gpu
+def test_frame_step_captured_in_a_hip_graph(miro):
+    """The whole step (trace -> shadow rays -> indirect trace -> shade) records into a HIP graph on the stream it is
+    given -- no hidden synchronisation or allocation inside the C ABI calls -- and replays to the same picture."""
+    b = product_scene(miro, "teapot")
+    fr = mframe.FrameRenderer(b, "teapot", 160, 120, spp=2)
+    fr.generate()
+    fr.step()
+    torch.cuda.synchronize()
+    ref, counts = fr.d_rgb.clone(), fr.ray_counts()
+    g = fr.capture()
+    for _ in range(3):
+        fr.d_rgb.zero_()
+        fr.d_hits.zero_()
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(fr.d_rgb, ref) and fr.ray_counts() == counts
