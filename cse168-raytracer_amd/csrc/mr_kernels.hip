@@ -57,12 +57,6 @@ __device__ __forceinline__ void slab_axis(float lo, float hi, float o, float d, 
     if (tfar < mx) mx = tfar;
 }
 
-__device__ __forceinline__ void slab_axis_fast(float lo, float hi, float o, float inv, float &mn, float &mx) {
-    const float t0 = (lo - o) * inv, t1 = (hi - o) * inv;
-    mn = fmaxf(mn, fminf(t0, t1));
-    mx = fminf(mx, fmaxf(t0, t1));
-}
-
 struct RayRegs {
     float ox, oy, oz, dx, dy, dz;     // origin, direction
     float ix, iy, iz;                 // 1/d
@@ -278,7 +272,8 @@ __device__ __forceinline__ void node_decide(float mn0, float mx0, float mn1, flo
     }
 }
 
-// SLAB: 0 = select form (the reference's NaN semantics), 1 = min/max on (corner - o) * (1/d), 2 = lean fma form
+// SLAB: 0 = select form (the reference's NaN semantics) on (corner - o) * (1/d), 1 = min/max on the same products,
+//       2 = lean fma form, 3 = select form on the reference's true quotients (corner - o) / d
 // SCALAR: try the wave-uniform scalar-load path first
 template <bool EXACT, bool STATS, int SLAB, bool SCALAR = false>
 __device__ __forceinline__ void node_step(const TraceParams &p, const RayRegs &r, Lane &L, int *s_stack, int tid, Stats &st) {
@@ -289,7 +284,7 @@ __device__ __forceinline__ void node_step(const TraceParams &p, const RayRegs &r
             const v16f v = load_node_scalar(p.nodes, cur0);
             node_slabs<EXACT, STATS, SLAB>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]),
                                            make_float4(v[8], v[9], v[10], v[11]), r, mn0, mx0, mn1, mx1);
-            node_decide<STATS, SLAB != 0>(mn0, mx0, mn1, mx1, __float_as_int(v[12]), __float_as_int(v[13]), r, L, s_stack, st);
+            node_decide<STATS, SLAB == 1 || SLAB == 2>(mn0, mx0, mn1, mx1, __float_as_int(v[12]), __float_as_int(v[13]), r, L, s_stack, st);
             return;
         }
     }
@@ -298,7 +293,7 @@ __device__ __forceinline__ void node_step(const TraceParams &p, const RayRegs &r
     const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2];
     const int4 q3 = *reinterpret_cast<const int4 *>(nd + 3);
     node_slabs<EXACT, STATS, SLAB>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
-    node_decide<STATS, SLAB != 0>(mn0, mx0, mn1, mx1, q3.x, q3.y, r, L, s_stack, st);
+    node_decide<STATS, SLAB == 1 || SLAB == 2>(mn0, mx0, mn1, mx1, q3.x, q3.y, r, L, s_stack, st);
 }
 
 template <bool EXACT, bool STATS, int SLAB>
@@ -307,14 +302,14 @@ __device__ __forceinline__ void node_slabs(const float4 q0, const float4 q1, con
     if (SLAB == 2) {
         slab_box_lean(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, r, mn0, mx0);
         slab_box_lean(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, r, mn1, mx1);
-    } else if (EXACT && SLAB == 0) {
+    } else if (EXACT && (SLAB == 0 || SLAB == 3)) {
         mn0 = -kInf; mx0 = kInf; mn1 = -kInf; mx1 = kInf;
-        slab_axis<STATS>(q0.x, q0.y, r.ox, r.dx, r.ix, mn0, mx0);
-        slab_axis<STATS>(q0.z, q0.w, r.oy, r.dy, r.iy, mn0, mx0);
-        slab_axis<STATS>(q2.x, q2.y, r.oz, r.dz, r.iz, mn0, mx0);
-        slab_axis<STATS>(q1.x, q1.y, r.ox, r.dx, r.ix, mn1, mx1);
-        slab_axis<STATS>(q1.z, q1.w, r.oy, r.dy, r.iy, mn1, mx1);
-        slab_axis<STATS>(q2.z, q2.w, r.oz, r.dz, r.iz, mn1, mx1);
+        slab_axis<SLAB == 3>(q0.x, q0.y, r.ox, r.dx, r.ix, mn0, mx0);
+        slab_axis<SLAB == 3>(q0.z, q0.w, r.oy, r.dy, r.iy, mn0, mx0);
+        slab_axis<SLAB == 3>(q2.x, q2.y, r.oz, r.dz, r.iz, mn0, mx0);
+        slab_axis<SLAB == 3>(q1.x, q1.y, r.ox, r.dx, r.ix, mn1, mx1);
+        slab_axis<SLAB == 3>(q1.z, q1.w, r.oy, r.dy, r.iy, mn1, mx1);
+        slab_axis<SLAB == 3>(q2.z, q2.w, r.oz, r.dz, r.iz, mn1, mx1);
     } else {
         slab_box_minmax(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, r, mn0, mx0);
         slab_box_minmax(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, r, mn1, mx1);
@@ -403,7 +398,10 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(TraceParams p) {
     const int tid = threadIdx.x;
     const unsigned long long stride = (unsigned long long)gridDim.x * kTraceBlock;
     Stats st = {0ull, 0ull};
-    constexpr bool kMinMax = !STATS && (VAR & 1);
+    // VAR bit 4: every slab distance is the reference's true quotient (MR_MATH_STRICT; MR_COUNT_STATS implies it)
+    constexpr bool kStrict = STATS || (VAR & 16);
+    constexpr int kBaseSlab = kStrict ? 3 : 0;
+    constexpr bool kMinMax = !kStrict && (VAR & 1);
     constexpr bool kWW = (VAR & 2) != 0;
     constexpr int kSafeSlab = (VAR & 4) ? 2 : 1;      // slab form for waves whose rays cannot produce a NaN
     constexpr bool kScalar = (VAR & 8) != 0;          // wave-uniform nodes through the scalar cache
@@ -433,9 +431,9 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(TraceParams p) {
         stack_reset(L, s_stack, tid);                 // this lane's LDS stack: the kDone sentinel only
         {   // BVH::intersect root test (BVH.cpp:447-466)
             float mn = -kInf, mx = kInf;
-            slab_axis<STATS>(p.root_lo[0], p.root_hi[0], r.ox, r.dx, r.ix, mn, mx);
-            slab_axis<STATS>(p.root_lo[1], p.root_hi[1], r.oy, r.dy, r.iy, mn, mx);
-            slab_axis<STATS>(p.root_lo[2], p.root_hi[2], r.oz, r.dz, r.iz, mn, mx);
+            slab_axis<kStrict>(p.root_lo[0], p.root_hi[0], r.ox, r.dx, r.ix, mn, mx);
+            slab_axis<kStrict>(p.root_lo[1], p.root_hi[1], r.oy, r.dy, r.iy, mn, mx);
+            slab_axis<kStrict>(p.root_lo[2], p.root_hi[2], r.oz, r.dz, r.iz, mn, mx);
             if (STATS && live) st.box++;
             L.cur = (live && !((mn > mx) || (mn > tmax0) || (mx < r.tmin))) ? p.root_ref : kDone;
         }
@@ -446,7 +444,7 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(TraceParams p) {
             if (__all(lane_is_nan_free(r) || !live)) traverse<EXACT, ANY, STATS, kSafeSlab, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
             else traverse<EXACT, ANY, STATS, 0, kWW, false, kObj>(p, r, L, s_stack, tid, st);
         } else {
-            traverse<EXACT, ANY, STATS, 0, kWW, false, kObj>(p, r, L, s_stack, tid, st);
+            traverse<EXACT, ANY, STATS, kBaseSlab, kWW, kStrict && kScalar, kObj>(p, r, L, s_stack, tid, st);
         }
 
         // Scene::trace's scan of the unbounded objects (Scene.cpp:220-230): every plane is tested against the
@@ -802,8 +800,12 @@ mr_status launch_trace(const TraceParams &p, uint32_t flags, hipStream_t stream)
         // scenes with spheres / planes: the exact kernel with the object dispatch compiled in (VAR bit 5); the fast
         // and persistent forms cover triangle scenes only
         if (stats) return any ? launch_trace_t<true, true, true, 32>(p, stream) : launch_trace_t<true, false, true, 32>(p, stream);
+        if (flags & MR_MATH_STRICT)
+            return any ? launch_trace_t<true, true, false, 58>(p, stream) : launch_trace_t<true, false, false, 58>(p, stream);
         return any ? launch_trace_t<true, true, false, 43>(p, stream) : launch_trace_t<true, false, false, 43>(p, stream);
     }
+    if (flags & MR_MATH_STRICT)   // true-division slabs, while-while, scalar path (VAR 16 | 2 | 8)
+        return any ? launch_trace_t<true, true, false, 26>(p, stream) : launch_trace_t<true, false, false, 26>(p, stream);
     if (stats) {
         // counting mode is diagnostic: always the strict-division exact kernel in the reference's control flow
         return any ? launch_trace_t<true, true, true, 0>(p, stream) : launch_trace_t<true, false, true, 0>(p, stream);

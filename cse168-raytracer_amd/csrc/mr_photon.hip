@@ -121,7 +121,6 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
     // node of this lane inside a block: level lv (0..5), offset within the level
     const int lv = 31 - __clz(lane + 1);
     const int off_in_level = lane + 1 - (1 << lv);
-    const int parent_lane = ((lane + 1) >> 1) - 1;
     const bool node_lane = lane < 63;
 
     for (unsigned long long q = wave_id; q < nq; q += n_waves) {
