@@ -804,12 +804,12 @@ mr_status launch_trace(const TraceParams &p, uint32_t flags, hipStream_t stream)
             return any ? launch_trace_t<true, true, false, 58>(p, stream) : launch_trace_t<true, false, false, 58>(p, stream);
         return any ? launch_trace_t<true, true, false, 43>(p, stream) : launch_trace_t<true, false, false, 43>(p, stream);
     }
-    if (flags & MR_MATH_STRICT)   // true-division slabs, while-while, scalar path (VAR 16 | 2 | 8)
-        return any ? launch_trace_t<true, true, false, 26>(p, stream) : launch_trace_t<true, false, false, 26>(p, stream);
     if (stats) {
         // counting mode is diagnostic: always the strict-division exact kernel in the reference's control flow
         return any ? launch_trace_t<true, true, true, 0>(p, stream) : launch_trace_t<true, false, true, 0>(p, stream);
     }
+    if (flags & MR_MATH_STRICT)   // true-division slabs, while-while, scalar path (VAR 16 | 2 | 8)
+        return any ? launch_trace_t<true, true, false, 26>(p, stream) : launch_trace_t<true, false, false, 26>(p, stream);
     // MR_MATH_FAST: lean fma slabs + fmaf/rcp triangle test, with the same scalar-cache path as the exact kernel (VAR 15)
     if (fast) return any ? launch_trace_t<false, true, false, 15>(p, stream) : launch_trace_t<false, false, false, 15>(p, stream);
     if (flags & MR_TRACE_PERSISTENT) return any ? launch_persistent<true, true, 16>(p, stream) : launch_persistent<true, false, 16>(p, stream);

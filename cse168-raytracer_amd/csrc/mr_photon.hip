@@ -146,9 +146,9 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
             const int b = w.stack[sp];                        // same address in every lane: LDS broadcast
             const float lb_block = w.lb[sp];
             if (lb_block >= r2) continue;                     // the plane that led here is no longer inside the radius
-            const long long jj = ((long long)b << lv) + off_in_level;
-            const bool valid = node_lane && jj <= (long long)pm.n;
-            const int j = valid ? (int)jj : 0;
+            const int jj = (b << lv) + off_in_level;          // < 2^24 (checked at launch)
+            const bool valid = node_lane && jj <= pm.n;
+            const int j = valid ? jj : 0;
             float4 A = make_float4(0.f, 0.f, 0.f, 0.f), D = make_float4(0.f, 0.f, 0.f, 0.f);
             if (valid) { A = pm.posplane[j]; D = pm.dir[j]; }
             const int plane = __float_as_int(A.w);
@@ -163,22 +163,26 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
             // from the index alone.  `path` collects the far-side steps (most significant = nearest the block root),
             // which is the order the reference's near-first recursion visits subtrees in; `lb` is the largest squared
             // plane distance crossed on the far side (a lower bound of the distance to anything below).
-            bool reach = valid;
+            // every ancestor inside the block must descend (index < half, :160); indices grow downwards, so the
+            // parent's test covers them all
+            bool reach = valid && (lv == 0 || (j >> 1) < pm.half);
             int path = 0;
             float lb = lb_block;
+            float a_d1[5];
 #pragma unroll
-            for (int s = 1; s <= 5; s++) {
+            for (int s = 1; s <= 5; s++) {                                          // five ds_bpermute in flight together
                 const int anc_lane = ((lane + 1) >> s) - 1;                         // -1 (-> lane 63, unused) above the root
-                const float a_d1 = __shfl(d1, anc_lane & 63, 64);
-                if (s <= lv) {
-                    const long long anc = jj >> s;                                   // the ancestor's tree index
-                    const bool is_right = ((jj >> (s - 1)) & 1) != 0, near_right = a_d1 > 0.0f;
-                    const bool far_step = is_right != near_right;
-                    const float pd2 = a_d1 * a_d1;
-                    reach = reach && anc < (long long)pm.half && (!far_step || pd2 < r2);
-                    path |= (far_step ? 1 : 0) << (s - 1);
-                    if (far_step) lb = fmaxf(lb, pd2);
-                }
+                a_d1[s - 1] = __shfl(d1, anc_lane & 63, 64);
+            }
+#pragma unroll
+            for (int s = 1; s <= 5; s++) {                                          // branch-free: `s <= lv` is a lane constant
+                // the low lv bits of the index are the lane's offset in its level: which side it is on is a lane constant
+                const bool is_right = ((off_in_level >> (s - 1)) & 1) != 0, near_right = a_d1[s - 1] > 0.0f;
+                const bool far_step = (s <= lv) && (is_right != near_right);
+                const float pd2 = a_d1[s - 1] * a_d1[s - 1];
+                reach = reach && (!far_step || pd2 < r2);
+                path |= (far_step ? 1 : 0) << (s - 1);
+                lb = (far_step && pd2 > lb) ? pd2 : lb;
             }
             // the photon itself (:177-186)
             float dd = A.x - qx;
