@@ -406,3 +406,40 @@ def test_full_size_properties(oracle, miro, torch_cuda, name, W, H, spp, closed)
     want = a.trace(sub)
     got = d_hits[idx].cpu().numpy().view(miro.HIT_DTYPE).reshape(-1)
     assert_hits_bit_exact(got, want.view(miro.HIT_DTYPE))
+
+
+def test_degenerate_triangles_and_coplanar_rays(oracle, miro, torch_cuda):
+    """Zero-area triangles (collinear / repeated vertices: n = 0, so t, beta, gamma are 0/0 or x/0), rays lying in a
+    triangle's plane (ddotn = 0 -> +-inf / NaN quotients) and rays through vertices of a fan: every comparison of
+    Triangle.cpp:158 falls the way IEEE arithmetic makes it fall, identically on both sides."""
+    rng = np.random.RandomState(7)
+    v = [(0, 0, 0), (1, 0, 0), (2, 0, 0),            # collinear
+         (0, 1, 0), (0, 1, 0), (1, 1, 0),            # repeated vertex
+         (3, 3, 3), (3, 3, 3), (3, 3, 3),            # a point
+         (-1, -1, 0), (2, -1, 0), (0.5, 2, 0),       # a proper triangle in z = 0
+         (0, 0, 1), (1, 0, 1), (0, 1, 1)]            # and one in z = 1
+    v = np.asarray(v, np.float32)
+    n = np.tile(np.asarray([[0, 0, 1]], np.float32), (len(v), 1))
+    f = np.arange(len(v), dtype=np.uint32).reshape(-1, 3)
+    a, b = oracle.Scene(), miro.Scene()
+    for s in (a, b):
+        s.add_arrays(v, n, f, f)
+        s.build(4)
+    rays = np.zeros(4000, oracle.RAY_DTYPE)
+    o = (rng.rand(4000, 3).astype(np.float32) - 0.3) * 4
+    d = rng.randn(4000, 3).astype(np.float32)
+    o[:1000, 2] = 0.0; d[:1000, 2] = 0.0              # in the plane z = 0: ddotn = 0 for the big triangle
+    o[1000:1500, 2] = 1.0; d[1000:1500, 2] = 0.0      # in the plane z = 1
+    tgt = v[rng.randint(0, len(v), 500)]              # straight at vertices (of degenerate triangles too)
+    d[1500:2000] = tgt - o[1500:2000]
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30).astype(np.float32)
+    rays["ox"], rays["oy"], rays["oz"] = o[:, 0], o[:, 1], o[:, 2]
+    rays["dx"], rays["dy"], rays["dz"] = d[:, 0], d[:, 1], d[:, 2]
+    rays["tmax"] = 1e12
+    want, ctr = a.trace(rays, counters=True)
+    assert (want["prim"] != oracle.MISS).any() and (want["prim"] == oracle.MISS).any()
+    assert_hits_bit_exact(b.trace(rays.view(miro.RAY_DTYPE)), want.view(miro.HIT_DTYPE))
+    assert_hits_bit_exact(b.trace(rays.view(miro.RAY_DTYPE), flags=miro.MR_MATH_STRICT), want.view(miro.HIT_DTYPE))
+    b.stats()
+    b.trace(rays.view(miro.RAY_DTYPE), flags=miro.MR_COUNT_STATS)
+    assert b.stats() == ctr
