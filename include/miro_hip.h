@@ -94,8 +94,8 @@ enum {
                                       of Triangle.cpp:150-156 and is what parity and the bench are quoted on */
     MR_COUNT_STATS    = 1u << 4,   /* accumulate -DSTATS counters (BVH.cpp:461,496,632,643) */
     MR_TRACE_PERSISTENT = 1u << 5, /* incoherent batches: resident waves pull rays from a counter and re-arm idle
-                                      lanes by wave64 ballot + prefix sum (same results; +19 % on random rays,
-                                      slower on coherent camera rays -- off by default) */
+                                      lanes by wave64 ballot + prefix sum (same results; on par with the default
+                                      kernel on random rays, slower on coherent camera rays -- off by default) */
     MR_MATH_STRICT    = 1u << 6    /* slab distances as the reference's true quotients (corner - o) / d (BVH.cpp:601-602)
                                       instead of products with the correctly rounded 1/d.  The default differs from
                                       the quotient by <= 2 ulp, which can flip a box comparison only on an exact tie

@@ -76,7 +76,7 @@ def main():
             r[:, 4:7] = dd
             r[:, 7] = 1e12
             hh = torch.empty((m, 4), device="cuda")
-            for label, flags in (("exact", 0), ("fast", miro_amd.MR_MATH_FAST)):
+            for label, flags in (("exact", 0), ("pers.", miro_amd.MR_TRACE_PERSISTENT), ("fast", miro_amd.MR_MATH_FAST)):
                 sc.trace_device(r, m, hh, flags, stream=stream)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
