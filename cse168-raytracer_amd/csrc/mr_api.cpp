@@ -384,7 +384,10 @@ mr_status mr_trace(mr_scene *s, const mr_ray *rays, uint64_t n, mr_hit *hits, ui
         return fail(MR_ERR_INVALID, "device ray/hit buffers must be 16-byte aligned");
     const mr_ray *d_rays = rays;
     mr_hit *d_hits = hits;
+    // host buffers go through the scene's staging buffers: one such call at a time (the call is synchronous anyway)
+    std::unique_lock<std::mutex> staged(s->stage_mutex, std::defer_lock);
     if (!rays_dev || !hits_dev) {
+        staged.lock();
         if ((st = ensure_stage(s, n)) != MR_OK) return st;
         if (!rays_dev) {
             MR_HIP_CHECK(hipMemcpyAsync(s->d_stage_rays, rays, n * sizeof(mr_ray), hipMemcpyHostToDevice, stream));

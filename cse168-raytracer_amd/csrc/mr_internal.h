@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <mutex>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -176,9 +177,12 @@ struct mr_scene {
     unsigned long long *d_stats = nullptr;
     unsigned long long *d_work_counters = nullptr;   // ring of kWorkCounters hand-out counters
     std::atomic<uint32_t> next_counter{0};
-    // grow-only staging buffers for host-pointer traces
+    // grow-only staging buffers for host-pointer traces; stage_mutex serialises the calls that use them, so that
+    // mr_trace may be called concurrently from several host threads (Scene::trace is const and re-entrant,
+    // Scene.cpp:112-115 calls it from every OpenMP worker)
     void *d_stage_rays = nullptr, *d_stage_hits = nullptr;
     uint64_t stage_cap = 0;
+    std::mutex stage_mutex;
     // grow-only per-primary-ray occlusion flags for mr_shade_direct
     uint8_t *d_occluded = nullptr;
     uint64_t occluded_cap = 0;

@@ -135,7 +135,11 @@ mr_status mr_scene_export_tree(const mr_scene *scene, float *corners6, int32_t *
 
 /* ---- Scene::trace, batched (Scene.cpp:214-268 -> BVH.cpp:438-658 -> Triangle.cpp:136-169) ------- */
 /* stream: a hipStream_t (NULL = default stream).  Host buffers are staged synchronously;
- * with both buffers on the device the call only enqueues work on `stream`. */
+ * with both buffers on the device the call only enqueues work on `stream`.
+ * Threads: a built scene is immutable and mr_trace / mr_trace_indirect may be called on it from several host
+ * threads at once, like the reference's const Scene::trace from its OpenMP workers (Scene.cpp:112-115); calls
+ * with host buffers take turns on the scene's staging buffers.  mr_shade_direct and mr_shade_accumulate keep
+ * per-scene scratch (occlusion flags, light scale): one such call in flight per scene. */
 mr_status mr_trace(mr_scene *scene, const mr_ray *rays, uint64_t n_rays, mr_hit *hits,
                    uint32_t flags, void *stream);
 /* Same, for a batch whose size was produced on the device (the compacted shadow batch of

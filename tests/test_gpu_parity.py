@@ -408,6 +408,47 @@ def test_full_size_properties(oracle, miro, torch_cuda, name, W, H, spp, closed)
     assert_hits_bit_exact(got, want.view(miro.HIT_DTYPE))
 
 
+def test_concurrent_host_threads(oracle, miro, torch_cuda):
+    """mr_trace from several host threads on one scene (the reference calls the const Scene::trace from every OpenMP
+    worker, Scene.cpp:112-115): host-buffer calls take turns on the staging buffers, device-buffer calls on separate
+    streams run side by side; every thread gets its own rays' hits."""
+    import threading
+    torch = torch_cuda
+    a, b = both(oracle, miro, "teapot")
+    sets = [random_rays(oracle.RAY_DTYPE, 30000 + 1000 * i, (-4, 0, -4), (4, 4, 4), seed=100 + i) for i in range(6)]
+    want = [a.trace(r).view(miro.HIT_DTYPE) for r in sets]
+    got, errs = [None] * len(sets), []
+
+    def host_worker(i):
+        try:
+            for _ in range(3):
+                got[i] = b.trace(sets[i].view(miro.RAY_DTYPE))
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    def device_worker(i):
+        try:
+            st = torch.cuda.Stream()
+            d_r = torch.from_numpy(sets[i].view(np.float32).reshape(-1, 8).copy()).cuda()
+            d_h = torch.empty((len(sets[i]), 4), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            for _ in range(3):
+                b.trace_device(d_r, len(sets[i]), d_h, stream=st)
+            st.synchronize()
+            got[i] = d_h.cpu().numpy().view(miro.HIT_DTYPE).reshape(-1)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    threads = [threading.Thread(target=host_worker if i % 2 == 0 else device_worker, args=(i,)) for i in range(len(sets))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for g, w in zip(got, want):
+        assert_hits_bit_exact(g, w)
+
+
 def test_degenerate_triangles_and_coplanar_rays(oracle, miro, torch_cuda):
     """Zero-area triangles (collinear / repeated vertices: n = 0, so t, beta, gamma are 0/0 or x/0), rays lying in a
     triangle's plane (ddotn = 0 -> +-inf / NaN quotients) and rays through vertices of a fan: every comparison of
