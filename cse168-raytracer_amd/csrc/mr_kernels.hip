@@ -368,7 +368,14 @@ __device__ __forceinline__ void leaf_step(const TraceParams &p, const RayRegs &r
             }
         }
     }
-    if (STATS) st.tri += cnt;
+    if (STATS) {
+        if (OBJ) {   // Stats::Ray_Tri_Intersect counts Triangle objects only (the dynamic_cast of BVH.cpp:496)
+            for (unsigned k = 0; k < cnt; k++)
+                if (__float_as_uint(p.tris[3 * (size_t)(first + k) + 2].w) != kSphereTag) st.tri++;
+        } else {
+            st.tri += cnt;
+        }
+    }
     if (ANY && done) {
         L.cur = kDone;
     } else {

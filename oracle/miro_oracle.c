@@ -584,7 +584,7 @@ static int isect_children(const orc_scene *s, int node, const orc_ray *r, float 
     if (nd->leaf) {
         for (int i = 0; i < nd->b; i++) {                             /* :493-509 */
             uint32_t prim = s->leaf_prims[nd->a + i];
-            ctr->tri_tests++;
+            if (!orc_is_sphere(s, prim)) ctr->tri_tests++;             /* :496 counts Triangle objects only */
             if (orc_obj_test(s, prim, r, tMin, minHit->t, &tmp)) {
                 if (tmp.t < minHit->t) { hit = 1; *minHit = tmp; }
             }
