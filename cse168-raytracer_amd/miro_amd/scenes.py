@@ -97,7 +97,7 @@ def sponza_path(cache_dir=None):
         return p
     cache_dir = cache_dir or os.environ.get("MIRO_CACHE_DIR") or os.path.join("/tmp", "miro_amd_cache_%d" % os.getuid())
     os.makedirs(cache_dir, exist_ok=True)
-    path = os.path.join(cache_dir, "atrium_standin_v2.obj")
+    path = os.path.join(cache_dir, "atrium_standin_v3.obj")
     if not os.path.exists(path):
         tmp = path + ".%d.tmp" % os.getpid()
         write_obj(tmp, *atrium_mesh())
@@ -129,7 +129,7 @@ def populate(scene, desc, cache_dir=None):
 
 
 # ---------------------------------------------------------------------------------------------
-# procedural stand-in for sponza.obj: a closed two-storey colonnaded atrium, ~66k triangles,
+# procedural stand-in for sponza.obj: a closed two-storey colonnaded atrium, ~77k triangles,
 # sized so that makeSponzaScene's camera (8,1.5,1)->(0,2.5,-1) and light (0,10,0) sit inside it.
 # Deterministic (no RNG beyond a fixed-seed relief), pure numpy.
 # ---------------------------------------------------------------------------------------------
@@ -201,7 +201,14 @@ class _MeshBuilder:
 
 
 def atrium_mesh():
-    """Returns (vertices float64 [nv,3], faces int [nt,3]).  ~66k triangles."""
+    """Returns (vertices float64 [nv,3], faces int [nt,3]).
+
+    Calibrated against what the reference's write-up publishes for the real sponza.obj under its own builder
+    (writeup/A2/Readme.tex:95-102): 42 645 BVH nodes, 54.8 node visits + 9.93 triangle tests per primary ray, 51.2 + 10.33
+    per ray with shadow rays.  This mesh: 76 552 triangles, 46 701 nodes, 51.9 + 10.50 per primary ray, 42.3 + 10.13 with
+    shadows (1920x1080 frame, counted by the restated traversal) -- i.e. about the real scene's work per ray, where a
+    plain tessellated box would need half of it.  What buys the visits is clutter that rays graze: slender posts on the
+    nave floor, long banners hanging along the view direction, a wire lantern around the light."""
     rng = np.random.RandomState(168)
     relief = rng.rand(64, 64)
 
@@ -212,13 +219,13 @@ def atrium_mesh():
 
     mb = _MeshBuilder()
     X0, X1, Y0, Y1, Z0, Z1 = -14.0, 14.0, 0.0, 12.0, -6.0, 6.0
-    # shell: floor, ceiling, four walls (inward-facing, relief on the long walls)
-    mb.grid((X0, Y0, Z0), (0, 0, Z1 - Z0), (X1 - X0, 0, 0), 40, 96)                 # floor
-    mb.grid((X0, Y1, Z0), (X1 - X0, 0, 0), (0, 0, Z1 - Z0), 28, 12)                  # ceiling
-    mb.grid((X0, Y0, Z0), (X1 - X0, 0, 0), (0, Y1 - Y0, 0), 72, 30, brick)           # wall z=Z0
-    mb.grid((X0, Y0, Z1), (0, Y1 - Y0, 0), (X1 - X0, 0, 0), 30, 72, brick)           # wall z=Z1
-    mb.grid((X0, Y0, Z0), (0, Y1 - Y0, 0), (0, 0, Z1 - Z0), 24, 24, brick)           # wall x=X0
-    mb.grid((X1, Y0, Z0), (0, 0, Z1 - Z0), (0, Y1 - Y0, 0), 24, 24, brick)           # wall x=X1
+    # shell: floor, ceiling, four walls (inward-facing, relief on the walls)
+    mb.grid((X0, Y0, Z0), (0, 0, Z1 - Z0), (X1 - X0, 0, 0), 20, 48)                 # floor
+    mb.grid((X0, Y1, Z0), (X1 - X0, 0, 0), (0, 0, Z1 - Z0), 14, 6)                   # ceiling
+    mb.grid((X0, Y0, Z0), (X1 - X0, 0, 0), (0, Y1 - Y0, 0), 36, 15, brick)           # wall z=Z0
+    mb.grid((X0, Y0, Z1), (0, Y1 - Y0, 0), (X1 - X0, 0, 0), 15, 36, brick)           # wall z=Z1
+    mb.grid((X0, Y0, Z0), (0, Y1 - Y0, 0), (0, 0, Z1 - Z0), 12, 12, brick)           # wall x=X0
+    mb.grid((X1, Y0, Z0), (0, 0, Z1 - Z0), (0, Y1 - Y0, 0), 12, 12, brick)           # wall x=X1
     # two storeys of colonnades along both long sides
     col_x = np.arange(-12.0, 12.0 + 1e-9, 3.0)
     for zc in (-3.5, 3.5):
@@ -243,7 +250,7 @@ def atrium_mesh():
         mb.grid((X0, 4.95, zlo), (0, 0, zhi - zlo), (X1 - X0, 0, 0), 6, 56)          # gallery floor (top)
         mb.grid((X0, 4.55, zlo), (X1 - X0, 0, 0), (0, 0, zhi - zlo), 56, 6)          # gallery underside
         mb.grid((X0, 4.55, zin), (X1 - X0, 0, 0), (0, 0.4, 0), 56, 1)                # fascia
-        for x in np.arange(-13.5, 13.5 + 1e-9, 0.5):
+        for x in np.arange(-13.5, 13.5 + 1e-9, 1.0):
             ys = np.linspace(4.95, 5.85, 7)
             prof = 0.045 * (1.0 + 0.8 * np.sin(np.pi * (ys - 4.95) / 0.9) ** 2)
             mb.tube(np.stack([np.full_like(ys, x), ys, np.full_like(ys, zin)], 1), prof, 8)
@@ -252,12 +259,40 @@ def atrium_mesh():
     for x0, amp in ((-7.0, 0.35), (3.5, 0.45), (10.5, 0.3)):
         def wave(s, t, amp=amp):
             return amp * np.sin(6 * np.pi * t) * (0.3 + 0.7 * s)
-        mb.grid((x0, 10.5, -2.4), (0, -3.5, 0), (0, 0, 4.8), 30, 42, wave)
+        mb.grid((x0, 10.5, -2.4), (0, -3.5, 0), (0, 0, 4.8), 20, 28, wave)
     # a few floor objects (vases) for small-scale geometry near the camera
     for x, z in ((5.0, -1.5), (5.0, 1.8), (2.0, 0.0), (-3.0, -1.0), (-8.0, 1.0), (9.5, -2.0)):
         ys = np.linspace(0.0, 1.2, 14)
         prof = 0.12 + 0.28 * np.sin(np.pi * ys / 1.2) ** 1.5 * (1.0 - 0.35 * ys / 1.2)
         mb.tube(np.stack([np.full_like(ys, x), ys, np.full_like(ys, z)], 1), prof, 24)
+    # clutter that rays graze (what makes the real scene expensive): slender posts scattered over the nave floor ...
+    prng = np.random.RandomState(5)
+    for _ in range(400):
+        x, z = prng.uniform(-13, 13), prng.uniform(-2.6, 2.6)
+        h = prng.uniform(1.0, 4.0)
+        ys = np.linspace(0.0, h, 6)
+        mb.tube(np.stack([np.full_like(ys, x), ys, np.full_like(ys, z)], 1), 0.03 + 0.05 * np.sin(np.pi * ys / h) ** 2, 5,
+                closed_caps=False)
+    # ... long banners hanging along the nave axis, i.e. along the view direction ...
+    for k in range(6):
+        z = -2.2 + 4.4 * (k + 0.5) / 6
+
+        def ripple(s, t, k=k):
+            return 0.15 * np.sin(9 * np.pi * t + k)
+        mb.grid((-13.0, 10.8, z), (0, -4.0 - (k % 2), 0), (26.0, 0, 0), 8, 60, ripple)
+    # ... and a wire lantern (two shells of meridians and parallels) around the light at (0, 10, 0)
+    c = np.array([0.0, 10.0, 0.0])
+    for shell in range(2):
+        rad = 1.6 * (1.0 + 0.45 * shell)
+        for k in range(12):
+            ph = 2 * np.pi * (k + 0.5 * shell) / 12
+            th = np.linspace(0.12, np.pi - 0.12, 14)
+            mb.tube(c + rad * np.stack([np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)], 1), 0.02, 5, closed_caps=False)
+        for k in range(6):
+            th = np.pi * (k + 1) / 7
+            ph = np.linspace(0, 2 * np.pi, 28)
+            mb.tube(c + rad * np.stack([np.sin(th) * np.cos(ph), np.full_like(ph, np.cos(th)), np.sin(th) * np.sin(ph)], 1),
+                    0.02, 5, closed_caps=False)
     return mb.finish()
 
 
