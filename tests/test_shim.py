@@ -96,3 +96,49 @@ def test_shim_spheres_and_planes(tmp_path, oracle, miro):
     ln = np.sqrt((N[:, 0] * N[:, 0] + N[:, 1] * N[:, 1]) + N[:, 2] * N[:, 2]).astype(np.float32)
     Nn = N * (np.float32(1) / ln)[:, None]                                                     # Scene.cpp:262
     assert np.array_equal(rec["f"][hit, 5:8].view(np.uint32), Nn[hit].view(np.uint32))
+
+
+def build_abi_frame(tmp_path, miro):
+    exe = str(tmp_path / "abi_frame")
+    lib_dir = os.path.dirname(miro.lib_path())
+    cmd = ["g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+           "-I", "/opt/rocm/include", os.path.join(ROOT, "tests", "cpp", "abi_frame.cpp"),
+           "-L", lib_dir, "-lmiro_hip", "-L", "/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_c_abi_frame_program_compiles_with_plain_gxx(tmp_path, miro):
+    """INTEGRATION.md section 3 as a program: the whole frame through the C ABI from C++ (g++, the header, the library
+    and the HIP runtime for device buffers -- no hipcc, no Python)."""
+    exe = build_abi_frame(tmp_path, miro)
+    assert subprocess.run([exe], capture_output=True).returncode == 2          # usage
+
+
+@pytest.mark.gpu
+def test_c_abi_frame_program_renders_the_oracles_picture(tmp_path, oracle, miro):
+    exe = build_abi_frame(tmp_path, miro)
+    d = scenes.SCENES["teapot"]
+    W, H, spp = 160, 120, 2
+    csv = lambda v: ",".join(str(float(x)) for x in v)
+    out = str(tmp_path / "frame.ppm")
+    floor = ",".join(str(float(x)) for tri in d["floor"] for x in tri)
+    r = subprocess.run([exe, scenes._model("teapot.obj"), floor, str(W), str(H), str(spp), csv(d["eye"]), csv(d["lookat"]),
+                        str(d["fov"]), csv(d["light"]), str(d["wattage"]), out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    raw = open(out, "rb").read()
+    header = ("P6\n%d %d\n255\n" % (W, H)).encode()
+    assert raw.startswith(header)
+    img = np.frombuffer(raw[len(header):], np.uint8).reshape(H * W, 3)
+    # the oracle's picture of the same frame
+    a = oracle_scene(oracle, "teapot")
+    rays = oracle.eye_rays(camera_of(oracle, "teapot"), W, H, spp=spp, jitter=True, seed=168)
+    hits = a.trace(rays)
+    sh, src = a.shadow_rays(rays, hits, d["light"])
+    occ = np.zeros(len(rays), np.uint8)
+    occ[src.astype(np.int64)] = a.trace(sh)["prim"] != oracle.MISS
+    want = oracle.tonemap(a.shade_direct(rays, hits, occ, d["light"], d["wattage"], spp=spp))
+    assert r.stdout.split() == ["rays", str(len(rays)), str(len(sh))]
+    assert np.abs(img.astype(np.int32) - want.astype(np.int32)).max() <= 1     # expf vs exp at a quantisation boundary
+    assert len(np.unique(img)) > 4 and (img == img[0]).all(axis=1).mean() < 0.9   # an actual (if dim: 700 W at 15 m) picture
