@@ -106,6 +106,8 @@ enum {
 typedef struct mr_scene mr_scene;
 
 /* ---- scene assembly: Scene::addObject / TriangleMesh::load / createSingleTriangle -------------- */
+/* A scene lives on one device; every call that touches it makes that device the calling thread's current HIP
+ * device (hipSetDevice) and leaves it so -- the intended deployment is one process (or thread) per GPU. */
 mr_status mr_scene_create(int32_t device, mr_scene **out);
 mr_status mr_scene_destroy(mr_scene *scene);
 /* copies the arrays; triangles are appended in order (assignment2.cpp:449-461) */
