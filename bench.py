@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--band", type=int, default=8, help="rows per interleaved band when sharding the image")
     ap.add_argument("--fast", action="store_true", help="MR_MATH_FAST (not the parity mode; never the default)")
-    ap.add_argument("--strict", action="store_true", help="MR_MATH_STRICT: slab distances by true division (about 1/3 of the speed)")
+    ap.add_argument("--strict", action="store_true", help="MR_MATH_STRICT: slab distances as the reference's exact quotients (about 20 %% slower)")
     ap.add_argument("--any-shadow", action="store_true", help="any-hit shadow batch (opaque scenes only)")
     ap.add_argument("--cpu-spp", type=int, default=8, help="samples per pixel of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -120,6 +120,36 @@ __device__ __forceinline__ void slab_box_minmax(float lox, float hix, float loy,
     mx = vmin3(vmax2(ax, bx), vmax2(ay, by), vmax2(az, bz));
 }
 
+// The reference's quotient (corner - o) / d without a division: with inv = RN(1/d) and q = RN(a * inv), one
+// correction step q' = fma(fma(-q, d, a), inv, q) is the correctly rounded a / d (Markstein's theorem; checked on this
+// GPU against v_div_* over 1.1e11 operand pairs incl. every mantissa of a and of d, tools/div_identity_probe.hip) as
+// long as nothing under- or overflows on the way.  Callers guarantee that: "regular" rays (lane_is_regular) on
+// "regular" nodes (flag in the node record) keep a, d, q well inside the normal range.
+__device__ __forceinline__ float exact_quot(float a, float d, float inv) {
+    const float q = a * inv;
+    return __builtin_fmaf(__builtin_fmaf(-q, d, a), inv, q);
+}
+
+// min/max slab test on those exact quotients: the reference's entry/exit distances themselves (up to the sign of a
+// zero), 12 VALU more per box than slab_box_minmax and none of its tie caveats.
+__device__ __forceinline__ void slab_box_exactq(float lox, float hix, float loy, float hiy, float loz, float hiz,
+                                                const RayRegs &r, float &mn, float &mx) {
+    const float ax = exact_quot(lox - r.ox, r.dx, r.ix), bx = exact_quot(hix - r.ox, r.dx, r.ix);
+    const float ay = exact_quot(loy - r.oy, r.dy, r.iy), by = exact_quot(hiy - r.oy, r.dy, r.iy);
+    const float az = exact_quot(loz - r.oz, r.dz, r.iz), bz = exact_quot(hiz - r.oz, r.dz, r.iz);
+    mn = vmax3(vmin2(ax, bx), vmin2(ay, by), vmin2(az, bz));
+    mx = vmin3(vmax2(ax, bx), vmax2(ay, by), vmax2(az, bz));
+}
+
+// magnitudes for which exact_quot is safe: direction components in [2^-40, 2^40], origin components 0 or in
+// [2^-36, 2^60] (node corners obey the same bound when the node record's flag is clear, mr_api.cpp), so that a non-zero
+// corner - o is at least 2^-59 and every intermediate stays a normal number
+__device__ __forceinline__ bool regular_dir(float d) { const float a = __builtin_fabsf(d); return a >= 0x1p-40f && a <= 0x1p40f; }
+__device__ __forceinline__ bool regular_pos(float o) { const float a = __builtin_fabsf(o); return a == 0.0f || (a >= 0x1p-36f && a <= 0x1p60f); }
+__device__ __forceinline__ bool lane_is_regular(const RayRegs &r) {
+    return regular_dir(r.dx) && regular_dir(r.dy) && regular_dir(r.dz) && regular_pos(r.ox) && regular_pos(r.oy) && regular_pos(r.oz);
+}
+
 // Lean slab test of one child box for NaN-free rays: 6 fma + 3 min + 3 max + max3 + min3.  Entry/exit
 // distances differ from (corner - o) * (1/d) by rounding only; the decisions taken from them (cull, order) are
 // protected by the epsilon padding of every box (BVH.cpp:75-79) -- see DESIGN.md section 5.
@@ -278,13 +308,20 @@ __device__ __forceinline__ void node_decide(float mn0, float mx0, float mn1, flo
 template <bool EXACT, bool STATS, int SLAB, bool SCALAR = false>
 __device__ __forceinline__ void node_step(const TraceParams &p, const RayRegs &r, Lane &L, int *s_stack, int tid, Stats &st) {
     float mn0, mx0, mn1, mx1;
+    constexpr bool kSafe = SLAB == 1 || SLAB == 2 || SLAB == 4;
     if (SCALAR) {
         const int cur0 = __builtin_amdgcn_readfirstlane(L.cur);
         if (__all(L.cur == cur0)) {
             const v16f v = load_node_scalar(p.nodes, cur0);
-            node_slabs<EXACT, STATS, SLAB>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]),
-                                           make_float4(v[8], v[9], v[10], v[11]), r, mn0, mx0, mn1, mx1);
-            node_decide<STATS, SLAB == 1 || SLAB == 2>(mn0, mx0, mn1, mx1, __float_as_int(v[12]), __float_as_int(v[13]), r, L, s_stack, st);
+            const float4 q0 = make_float4(v[0], v[1], v[2], v[3]), q1 = make_float4(v[4], v[5], v[6], v[7]);
+            const float4 q2 = make_float4(v[8], v[9], v[10], v[11]);
+            if (SLAB == 4 && __float_as_int(v[14]) != 0) {   // irregular node (wave-uniform): the reference's own divisions
+                node_slabs<EXACT, STATS, 3>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
+                node_decide<STATS, false>(mn0, mx0, mn1, mx1, __float_as_int(v[12]), __float_as_int(v[13]), r, L, s_stack, st);
+                return;
+            }
+            node_slabs<EXACT, STATS, SLAB>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
+            node_decide<STATS, kSafe>(mn0, mx0, mn1, mx1, __float_as_int(v[12]), __float_as_int(v[13]), r, L, s_stack, st);
             return;
         }
     }
@@ -292,8 +329,13 @@ __device__ __forceinline__ void node_step(const TraceParams &p, const RayRegs &r
     const float4 *nd = p.nodes + 4 * (size_t)L.cur;
     const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2];
     const int4 q3 = *reinterpret_cast<const int4 *>(nd + 3);
+    if (SLAB == 4 && q3.z != 0) {
+        node_slabs<EXACT, STATS, 3>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
+        node_decide<STATS, false>(mn0, mx0, mn1, mx1, q3.x, q3.y, r, L, s_stack, st);
+        return;
+    }
     node_slabs<EXACT, STATS, SLAB>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
-    node_decide<STATS, SLAB == 1 || SLAB == 2>(mn0, mx0, mn1, mx1, q3.x, q3.y, r, L, s_stack, st);
+    node_decide<STATS, kSafe>(mn0, mx0, mn1, mx1, q3.x, q3.y, r, L, s_stack, st);
 }
 
 template <bool EXACT, bool STATS, int SLAB>
@@ -302,6 +344,9 @@ __device__ __forceinline__ void node_slabs(const float4 q0, const float4 q1, con
     if (SLAB == 2) {
         slab_box_lean(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, r, mn0, mx0);
         slab_box_lean(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, r, mn1, mx1);
+    } else if (SLAB == 4) {
+        slab_box_exactq(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, r, mn0, mx0);
+        slab_box_exactq(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, r, mn1, mx1);
     } else if (EXACT && (SLAB == 0 || SLAB == 3)) {
         mn0 = -kInf; mx0 = kInf; mn1 = -kInf; mx1 = kInf;
         slab_axis<SLAB == 3>(q0.x, q0.y, r.ox, r.dx, r.ix, mn0, mx0);
@@ -450,6 +495,12 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(TraceParams p) {
             // with o, d and 1/d all finite in every lane the select form and the min/max form decide identically
             if (__all(lane_is_nan_free(r) || !live)) traverse<EXACT, ANY, STATS, kSafeSlab, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
             else traverse<EXACT, ANY, STATS, 0, kWW, false, kObj>(p, r, L, s_stack, tid, st);
+        } else if (kStrict && !STATS) {
+            // MR_MATH_STRICT: exact quotients by the correction step where every lane's ray is regular (then the lanes'
+            // quotients are NaN-free too and the min/max form decides like the select form); the reference's own
+            // divisions otherwise
+            if (__all(lane_is_regular(r) || !live)) traverse<EXACT, ANY, STATS, 4, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
+            else traverse<EXACT, ANY, STATS, 3, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
         } else {
             traverse<EXACT, ANY, STATS, kBaseSlab, kWW, kStrict && kScalar, kObj>(p, r, L, s_stack, tid, st);
         }

@@ -121,6 +121,8 @@ def test_t_interval_and_degenerate_rays(oracle, miro, torch_cuda):
     neg0 = ax.copy(); neg0["dx"] = np.where(neg0["dx"] == 0, np.float32(-0.0), neg0["dx"]); cases.append(neg0)
     for rays in cases:
         assert_hits_bit_exact(b.trace(rays.view(miro.RAY_DTYPE)), a.trace(rays).view(miro.HIT_DTYPE))
+        # MR_MATH_STRICT: axis-parallel and zero directions are "irregular" rays -> the literal-division fallback
+        assert_hits_bit_exact(b.trace(rays.view(miro.RAY_DTYPE), flags=miro.MR_MATH_STRICT), a.trace(rays).view(miro.HIT_DTYPE))
     # the bound cases really exercise both sides
     assert (a.trace(cases[0])["prim"] == oracle.MISS).all()
     assert (a.trace(cases[1])["prim"] != oracle.MISS).all()
@@ -406,6 +408,33 @@ def test_full_size_properties(oracle, miro, torch_cuda, name, W, H, spp, closed)
     want = a.trace(sub)
     got = d_hits[idx].cpu().numpy().view(miro.HIT_DTYPE).reshape(-1)
     assert_hits_bit_exact(got, want.view(miro.HIT_DTYPE))
+
+
+@pytest.mark.parametrize("scale", [1e-15, 1e-9, 1.0, 1e12, 1e22])
+def test_strict_mode_across_magnitudes(oracle, miro, torch_cuda, scale):
+    """MR_MATH_STRICT takes the fma correction step only for operands well inside the normal range and divides like the
+    reference otherwise: the same mesh at coordinates from 1e-15 to 1e22 (irregular nodes and rays at both ends), rays
+    with direction components down to 1e-20, and the empty leaves of a degenerate tree all give the oracle's hits."""
+    rng = np.random.RandomState(11)
+    v0, _, vi, _ = both(oracle, miro, "sphere")[0].arrays()
+    v = (v0.astype(np.float64) * scale).astype(np.float32)
+    v = np.concatenate([v, np.tile(v[:3], (12, 1))])                        # 12 coincident triangles: a deep chain with empty leaves
+    f = np.concatenate([vi, np.arange(len(v0), len(v0) + 36, dtype=np.uint32).reshape(-1, 3)])
+    n = np.tile(np.asarray([[0, 0, 1]], np.float32), (len(v), 1))
+    a, b = oracle.Scene(), miro.Scene()
+    for s in (a, b):
+        s.add_arrays(v, n, f, f)
+        s.build(4)
+    lo, hi = v.min(0), v.max(0)
+    rays = random_rays(oracle.RAY_DTYPE, 6000, lo, hi, seed=4, tmax=np.float32(1e30))
+    tiny = rng.rand(2000) < 0.5                                             # some direction components far below 2^-40
+    rays["dx"][:2000] = np.where(tiny, np.float32(1e-20), rays["dx"][:2000])
+    rays["dz"][1000:3000] *= np.float32(1e-14)
+    want = a.trace(rays).view(miro.HIT_DTYPE)
+    # (at 1e22 the cross products of Triangle.cpp:151 overflow: every test is inf/NaN and everything misses, on both sides)
+    assert (want["prim"] != oracle.MISS).any() or scale > 1e15
+    assert_hits_bit_exact(b.trace(rays.view(miro.RAY_DTYPE), flags=miro.MR_MATH_STRICT), want)
+    assert_hits_bit_exact(b.trace(rays.view(miro.RAY_DTYPE)), want)
 
 
 def test_concurrent_host_threads(oracle, miro, torch_cuda):
