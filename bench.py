@@ -114,7 +114,9 @@ def main():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--band", type=int, default=8, help="rows per interleaved band when sharding the image")
     ap.add_argument("--fast", action="store_true", help="MR_MATH_FAST (not the parity mode; never the default)")
-    ap.add_argument("--strict", action="store_true", help="MR_MATH_STRICT: slab distances as the reference's exact quotients (about 20 %% slower)")
+    ap.add_argument("--product", action="store_true",
+                    help="MR_MATH_PRODUCT: slab distances as products with the rounded 1/d (about 25 %% faster; decisions can "
+                         "differ from the reference's on 2-ulp ties)")
     ap.add_argument("--any-shadow", action="store_true", help="any-hit shadow batch (opaque scenes only)")
     ap.add_argument("--cpu-spp", type=int, default=8, help="samples per pixel of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -155,7 +157,7 @@ def main():
 
     W, H, spp = a.width, a.height, a.spp
     bands = mframe.band_rows(H, a.band, rank, world)
-    flags = miro_amd.MR_MATH_FAST if a.fast else (miro_amd.MR_MATH_STRICT if a.strict else 0)
+    flags = miro_amd.MR_MATH_FAST if a.fast else (miro_amd.MR_MATH_PRODUCT if a.product else 0)
     stream = torch.cuda.current_stream()
 
     (Vp, Tp), (Vs, Ts), _ = reference_counts(scene, (desc, W, H, bands, 168), desc["light"])
@@ -244,9 +246,9 @@ def main():
             "config": {
                 "workload": workload,
                 "scene_triangles": int(info.n_triangles), "bvh_nodes": int(info.n_nodes),
-                "rays_per_step": int(rays_per_step), "math": "fast" if a.fast else ("strict (true-quotient slabs)" if a.strict else
-                                                   "exact (hits bit-identical to the reference scalar path; slab distances "
-                                                   "as products with the rounded 1/d, MR_MATH_STRICT for true quotients)"),
+                "rays_per_step": int(rays_per_step), "math": "fast" if a.fast else (
+                    "exact triangle test, slab distances as products with the rounded 1/d (MR_MATH_PRODUCT)" if a.product else
+                    "exact: every quotient of the reference's slab and triangle tests, bit for bit"),
                 "shadow_query": "any-hit" if a.any_shadow else "closest-hit (as Phong.cpp:97)",
                 "parallelism": "image rows in interleaved bands of %d over %d GPU(s), scene replicated, 1 RCCL gather of the framebuffer" % (a.band, world),
                 "resident_bytes_per_gpu": int(fr.bytes_resident() + info.device_bytes),

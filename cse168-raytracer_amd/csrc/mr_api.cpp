@@ -89,7 +89,7 @@ mr_status flatten_and_upload(mr_scene *s) {
         q[1] = make_float4(c1.lo[0], c1.hi[0], c1.lo[1], c1.hi[1]);
         q[2] = make_float4(c0.lo[2], c0.hi[2], c1.lo[2], c1.hi[2]);
         // refs[2] = 1 marks an "irregular" node: some child corner is not finite (empty leaves keep [inf,-inf]) or lies
-        // outside 0 / [2^-36, 2^60] in magnitude; MR_MATH_STRICT then divides like the reference instead of using the
+        // outside 0 / [2^-36, 2^60] in magnitude; the default trace then divides like the reference instead of using the
         // correction step (mr_kernels.hip: exact_quot)
         int32_t irregular = 0;
         for (const HostNode *c : {&c0, &c1})

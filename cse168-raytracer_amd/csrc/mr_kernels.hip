@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(TraceParams p) {
     const int tid = threadIdx.x;
     const unsigned long long stride = (unsigned long long)gridDim.x * kTraceBlock;
     Stats st = {0ull, 0ull};
-    // VAR bit 4: every slab distance is the reference's true quotient (MR_MATH_STRICT; MR_COUNT_STATS implies it)
+    // VAR bit 4: every slab distance is the reference's true quotient (the default trace; MR_COUNT_STATS implies it)
     constexpr bool kStrict = STATS || (VAR & 16);
     constexpr int kBaseSlab = kStrict ? 3 : 0;
     constexpr bool kMinMax = !kStrict && (VAR & 1);
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(TraceParams p) {
             if (__all(lane_is_nan_free(r) || !live)) traverse<EXACT, ANY, STATS, kSafeSlab, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
             else traverse<EXACT, ANY, STATS, 0, kWW, false, kObj>(p, r, L, s_stack, tid, st);
         } else if (kStrict && !STATS) {
-            // MR_MATH_STRICT: exact quotients by the correction step where every lane's ray is regular (then the lanes'
+            // the default trace: exact quotients by the correction step where every lane's ray is regular (then the lanes'
             // quotients are NaN-free too and the min/max form decides like the select form); the reference's own
             // divisions otherwise
             if (__all(lane_is_regular(r) || !live)) traverse<EXACT, ANY, STATS, 4, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
@@ -854,24 +854,25 @@ static mr_status launch_exact(const TraceParams &p, hipStream_t stream) {
 mr_status launch_trace(const TraceParams &p, uint32_t flags, hipStream_t stream) {
     if (p.n == 0) return MR_OK;
     const bool fast = flags & MR_MATH_FAST, any = flags & MR_TRACE_ANY, stats = flags & MR_COUNT_STATS;
+    const bool product = flags & MR_MATH_PRODUCT;
     if (p.n_planes || p.n_spheres) {
-        // scenes with spheres / planes: the exact kernel with the object dispatch compiled in (VAR bit 5); the fast
+        // scenes with spheres / planes: the exact kernels with the object dispatch compiled in (VAR bit 5); the fast
         // and persistent forms cover triangle scenes only
         if (stats) return any ? launch_trace_t<true, true, true, 32>(p, stream) : launch_trace_t<true, false, true, 32>(p, stream);
-        if (flags & MR_MATH_STRICT)
-            return any ? launch_trace_t<true, true, false, 58>(p, stream) : launch_trace_t<true, false, false, 58>(p, stream);
-        return any ? launch_trace_t<true, true, false, 43>(p, stream) : launch_trace_t<true, false, false, 43>(p, stream);
+        if (product) return any ? launch_trace_t<true, true, false, 43>(p, stream) : launch_trace_t<true, false, false, 43>(p, stream);
+        return any ? launch_trace_t<true, true, false, 58>(p, stream) : launch_trace_t<true, false, false, 58>(p, stream);
     }
     if (stats) {
-        // counting mode is diagnostic: always the strict-division exact kernel in the reference's control flow
+        // counting mode is diagnostic: always the literal-division kernel in the reference's control flow
         return any ? launch_trace_t<true, true, true, 0>(p, stream) : launch_trace_t<true, false, true, 0>(p, stream);
     }
-    if (flags & MR_MATH_STRICT)   // true-division slabs, while-while, scalar path (VAR 16 | 2 | 8)
-        return any ? launch_trace_t<true, true, false, 26>(p, stream) : launch_trace_t<true, false, false, 26>(p, stream);
-    // MR_MATH_FAST: lean fma slabs + fmaf/rcp triangle test, with the same scalar-cache path as the exact kernel (VAR 15)
+    // MR_MATH_FAST: lean fma slabs + fmaf/rcp triangle test, with the same scalar-cache path as the exact kernels (VAR 15)
     if (fast) return any ? launch_trace_t<false, true, false, 15>(p, stream) : launch_trace_t<false, false, false, 15>(p, stream);
     if (flags & MR_TRACE_PERSISTENT) return any ? launch_persistent<true, true, 16>(p, stream) : launch_persistent<true, false, 16>(p, stream);
-    return any ? launch_exact<true>(p, stream) : launch_exact<false>(p, stream);
+    // MR_MATH_PRODUCT: slab distances as products with the rounded 1/d (and its development variants)
+    if (product) return any ? launch_exact<true>(p, stream) : launch_exact<false>(p, stream);
+    // default: the reference's quotients by the correction step, while-while, scalar path (VAR 16 | 2 | 8)
+    return any ? launch_trace_t<true, true, false, 26>(p, stream) : launch_trace_t<true, false, false, 26>(p, stream);
 }
 
 mr_status launch_eye_rays(const mr_camera &cam, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,

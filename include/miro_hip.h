@@ -94,15 +94,16 @@ enum {
                                       of Triangle.cpp:150-156 and is what parity and the bench are quoted on */
     MR_COUNT_STATS    = 1u << 4,   /* accumulate -DSTATS counters (BVH.cpp:461,496,632,643) */
     MR_TRACE_PERSISTENT = 1u << 5, /* incoherent batches: resident waves pull rays from a counter and re-arm idle
-                                      lanes by wave64 ballot + prefix sum (same results; on par with the default
-                                      kernel on random rays, slower on coherent camera rays -- off by default) */
-    MR_MATH_STRICT    = 1u << 6    /* slab distances as the reference's true quotients (corner - o) / d (BVH.cpp:601-602)
-                                      instead of products with the correctly rounded 1/d.  The default differs from
-                                      the quotient by <= 2 ulp, which can flip a box comparison only on an exact tie
-                                      (observed: 0 of 3e8 rays in normal use, 2 of 1.3e8 when tMax is set one ulp
-                                      above a known hit); this flag removes even that.  The quotients come from one
-                                      fma correction step per product (exactly the correctly rounded quotient for
-                                      operands in the normal range; true divisions otherwise): about 20 % slower */
+                                      lanes by wave64 ballot + prefix sum (implies MR_MATH_PRODUCT; on par with the
+                                      one-shot kernel on random rays, slower on coherent camera rays -- off by default) */
+    MR_MATH_PRODUCT   = 1u << 6    /* slab distances as products (corner - o) * RN(1/d) instead of the reference's
+                                      quotients (corner - o) / d (BVH.cpp:601-602), which the default reproduces bit for
+                                      bit (one fma correction step per product: exactly the correctly rounded quotient
+                                      for operands in the normal range; literal divisions otherwise).  A product differs
+                                      from the quotient by <= 2 ulp, which can flip a box comparison only on an exact
+                                      tie (observed: 0 of 3e8 rays in normal use, 2 of 1.3e8 when tMax is set one ulp
+                                      above a known hit); t / beta / gamma of a hit are the same bits either way.
+                                      About 25 % faster */
 };
 
 typedef struct mr_scene mr_scene;

@@ -43,7 +43,7 @@ def test_device_reproduces_golden_hits(miro, name):
     rays, hits, ctr = load(name)
     b = product_scene(miro, name)
     r = rays.view(miro.RAY_DTYPE).reshape(-1)
-    for flags in (0, miro.MR_MATH_STRICT):
+    for flags in (0, miro.MR_MATH_PRODUCT):
         got = b.trace(r, flags=flags)
         assert np.array_equal(got.view(np.uint32).reshape(-1, 4), hits)
     b.stats()

@@ -51,9 +51,10 @@ def test_primary_rays_bit_exact(oracle, miro, torch_cuda, name, W, H):
 
 
 @pytest.mark.parametrize("name", ["teapot", "bunny", "sponza"])
-def test_strict_division_mode_bit_exact(oracle, miro, torch_cuda, name):
-    """MR_MATH_STRICT (slab distances as true quotients, BVH.cpp:601-602): same hits as the oracle and as the default
-    mode on camera, shadow and random rays, including closest/any agreement on hit or miss."""
+def test_quotient_and_product_slabs_bit_exact(oracle, miro, torch_cuda, name):
+    """The default trace (slab distances as the reference's quotients, BVH.cpp:601-602, by the fma correction step) and
+    MR_MATH_PRODUCT (products with the rounded 1/d): same hits as the oracle on camera, shadow and random rays,
+    including closest/any agreement on hit or miss."""
     a, b = both(oracle, miro, name)
     rays = oracle.eye_rays(camera_of(oracle, name), 160, 120)
     hits = a.trace(rays)
@@ -62,11 +63,11 @@ def test_strict_division_mode_bit_exact(oracle, miro, torch_cuda, name):
     rnd = random_rays(oracle.RAY_DTYPE, 20000, np.maximum(lo, -20), np.minimum(hi, 20), seed=21)
     allr = np.concatenate([rays, sh, rnd])
     want = a.trace(allr).view(miro.HIT_DTYPE)
-    strict = b.trace(allr.view(miro.RAY_DTYPE), flags=miro.MR_MATH_STRICT)
-    assert_hits_bit_exact(strict, want)
     assert_hits_bit_exact(b.trace(allr.view(miro.RAY_DTYPE)), want)
-    anyh = b.trace(allr.view(miro.RAY_DTYPE), flags=miro.MR_MATH_STRICT | miro.MR_TRACE_ANY)
-    assert np.array_equal(anyh["prim"] == oracle.MISS, want["prim"] == oracle.MISS)
+    assert_hits_bit_exact(b.trace(allr.view(miro.RAY_DTYPE), flags=miro.MR_MATH_PRODUCT), want)
+    for fl in (miro.MR_TRACE_ANY, miro.MR_MATH_PRODUCT | miro.MR_TRACE_ANY):
+        anyh = b.trace(allr.view(miro.RAY_DTYPE), flags=fl)
+        assert np.array_equal(anyh["prim"] == oracle.MISS, want["prim"] == oracle.MISS)
 
 
 @pytest.mark.parametrize("name", ["teapot", "bunny", "sponza"])
@@ -121,8 +122,8 @@ def test_t_interval_and_degenerate_rays(oracle, miro, torch_cuda):
     neg0 = ax.copy(); neg0["dx"] = np.where(neg0["dx"] == 0, np.float32(-0.0), neg0["dx"]); cases.append(neg0)
     for rays in cases:
         assert_hits_bit_exact(b.trace(rays.view(miro.RAY_DTYPE)), a.trace(rays).view(miro.HIT_DTYPE))
-        # MR_MATH_STRICT: axis-parallel and zero directions are "irregular" rays -> the literal-division fallback
-        assert_hits_bit_exact(b.trace(rays.view(miro.RAY_DTYPE), flags=miro.MR_MATH_STRICT), a.trace(rays).view(miro.HIT_DTYPE))
+        # (in the default trace, axis-parallel and zero directions are "irregular" rays -> the literal-division fallback)
+        assert_hits_bit_exact(b.trace(rays.view(miro.RAY_DTYPE), flags=miro.MR_MATH_PRODUCT), a.trace(rays).view(miro.HIT_DTYPE))
     # the bound cases really exercise both sides
     assert (a.trace(cases[0])["prim"] == oracle.MISS).all()
     assert (a.trace(cases[1])["prim"] != oracle.MISS).all()
@@ -381,21 +382,22 @@ def test_full_size_properties(oracle, miro, torch_cuda, name, W, H, spp, closed)
     # padded box, so a subtree that a huge tMax lets the ray enter is culled by `minOverlap > tMax`, BVH.cpp:609, once
     # tMax is near t): 3 of the bunny's 16.7 M rays turn into misses.  That is reference behaviour -- the rows that
     # change must be few, must be misses, and must be exactly what the oracle returns for the shortened ray.
-    # This is also the one place where the default kernel's slab arithmetic -- (corner - o) * (1/d) with a correctly
-    # rounded reciprocal, within 2 ulp of the reference's quotient -- can take a different decision: tMax now sits one
-    # ulp above t, and a box whose entry distance ties with it is culled or kept depending on that last ulp (2 of the
-    # 132.7 M sponza rays).  MR_MATH_STRICT divides like the reference and must agree with the oracle on every row.
     changed = (d_hits2.view(torch.int32) != hits_bits).any(dim=1).nonzero()[:, 0]
     assert len(changed) <= max(1, n // 1_000_000)
     if len(changed):
         assert bool((d_hits2.view(torch.int32)[changed, 1] == -1).all())
         sub = r2[changed].cpu().numpy().view(oracle.RAY_DTYPE).reshape(-1)
-        want_changed = a.trace(sub).view(miro.HIT_DTYPE)
-        got_default = d_hits2[changed].cpu().numpy().view(miro.HIT_DTYPE).reshape(-1)
-        tie_flips = (got_default.view(np.uint32).reshape(-1, 4) != want_changed.view(np.uint32).reshape(-1, 4)).any(axis=1)
-        assert tie_flips.sum() <= max(1, n // 50_000_000)
-        strict = b.trace(sub.view(miro.RAY_DTYPE), flags=binding.MR_MATH_STRICT)
-        assert_hits_bit_exact(strict, want_changed)
+        assert_hits_bit_exact(d_hits2[changed].cpu().numpy().view(miro.HIT_DTYPE).reshape(-1), a.trace(sub).view(miro.HIT_DTYPE))
+    # This is also the one place where MR_MATH_PRODUCT's slab arithmetic -- (corner - o) * (1/d) with a correctly
+    # rounded reciprocal, within 2 ulp of the reference's quotient -- can take a different decision than the default:
+    # tMax now sits one ulp above t, and a box whose entry distance ties with it is culled or kept depending on that
+    # last ulp (2 of the 132.7 M sponza rays).
+    d_hits3 = torch.empty_like(d_hits)
+    b.trace_device(r2, n, d_hits3, flags=binding.MR_MATH_PRODUCT)
+    torch.cuda.synchronize()
+    tie_flips = int((d_hits3.view(torch.int32) != d_hits2.view(torch.int32)).any(dim=1).sum())
+    assert tie_flips <= max(1, n // 50_000_000)
+    del d_hits3
     # (3) tMax = t: no hit can be the old one
     r2[:, 7] = d_hits[:, 0]
     b.trace_device(r2, n, d_hits2)
@@ -411,9 +413,9 @@ def test_full_size_properties(oracle, miro, torch_cuda, name, W, H, spp, closed)
 
 
 @pytest.mark.parametrize("scale", [1e-15, 1e-9, 1.0, 1e12, 1e22])
-def test_strict_mode_across_magnitudes(oracle, miro, torch_cuda, scale):
-    """MR_MATH_STRICT takes the fma correction step only for operands well inside the normal range and divides like the
-    reference otherwise: the same mesh at coordinates from 1e-15 to 1e22 (irregular nodes and rays at both ends), rays
+def test_exact_quotients_across_magnitudes(oracle, miro, torch_cuda, scale):
+    """The default trace takes the fma correction step only for operands well inside the normal range and divides like
+    the reference otherwise: the same mesh at coordinates from 1e-15 to 1e22 (irregular nodes and rays at both ends), rays
     with direction components down to 1e-20, and the empty leaves of a degenerate tree all give the oracle's hits."""
     rng = np.random.RandomState(11)
     v0, _, vi, _ = both(oracle, miro, "sphere")[0].arrays()
@@ -433,8 +435,8 @@ def test_strict_mode_across_magnitudes(oracle, miro, torch_cuda, scale):
     want = a.trace(rays).view(miro.HIT_DTYPE)
     # (at 1e22 the cross products of Triangle.cpp:151 overflow: every test is inf/NaN and everything misses, on both sides)
     assert (want["prim"] != oracle.MISS).any() or scale > 1e15
-    assert_hits_bit_exact(b.trace(rays.view(miro.RAY_DTYPE), flags=miro.MR_MATH_STRICT), want)
     assert_hits_bit_exact(b.trace(rays.view(miro.RAY_DTYPE)), want)
+    assert_hits_bit_exact(b.trace(rays.view(miro.RAY_DTYPE), flags=miro.MR_MATH_PRODUCT), want)
 
 
 def test_concurrent_host_threads(oracle, miro, torch_cuda):
@@ -509,7 +511,7 @@ def test_degenerate_triangles_and_coplanar_rays(oracle, miro, torch_cuda):
     want, ctr = a.trace(rays, counters=True)
     assert (want["prim"] != oracle.MISS).any() and (want["prim"] == oracle.MISS).any()
     assert_hits_bit_exact(b.trace(rays.view(miro.RAY_DTYPE)), want.view(miro.HIT_DTYPE))
-    assert_hits_bit_exact(b.trace(rays.view(miro.RAY_DTYPE), flags=miro.MR_MATH_STRICT), want.view(miro.HIT_DTYPE))
+    assert_hits_bit_exact(b.trace(rays.view(miro.RAY_DTYPE), flags=miro.MR_MATH_PRODUCT), want.view(miro.HIT_DTYPE))
     b.stats()
     b.trace(rays.view(miro.RAY_DTYPE), flags=miro.MR_COUNT_STATS)
     assert b.stats() == ctr

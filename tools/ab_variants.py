@@ -31,7 +31,7 @@ def child(a):
         sc = miro_amd.Scene(0)
         scenes.populate(sc, name)
         sc.build(4)
-        fr = mframe.FrameRenderer(sc, name, a.w, a.h, spp=a.spp)
+        fr = mframe.FrameRenderer(sc, name, a.w, a.h, spp=a.spp, flags=miro_amd.MR_MATH_PRODUCT)   # the variants are forms of the product kernel
         fr.generate()
         fr.trace_primary()
         fr.make_shadow_rays()
@@ -54,7 +54,7 @@ def child(a):
         r[:, 4:7] = dd / dd.norm(dim=1, keepdim=True)
         r[:, 7] = 1e12
         hh = torch.empty((m, 4), device="cuda")
-        sc.trace_device(r, m, hh)
+        sc.trace_device(r, m, hh, miro_amd.MR_MATH_PRODUCT)
         torch.cuda.synchronize()
         out[name + ".incoherent"] = checksum(hh)
         out[name + ".rays"] = [n_p, n_s, m]
