@@ -2,7 +2,7 @@
 (primary batch, shadow batch, incoherent batch).  Each variant runs in its own process (the variant is read
 once from MIRO_TRACE_VARIANT); a position-weighted 64-bit checksum of the hit bits is compared.
 
-usage: python tools/ab_variants.py [--spp 16] [--variants 0,3,7,9]
+usage: python tools/ab_variants.py [--spp 16] [--variants 0,3,7,9,11,q]   (q = the default trace with exact quotients)
 """
 import argparse
 import json
@@ -27,11 +27,13 @@ def child(a):
     import miro_amd
     from miro_amd import frame as mframe, scenes
     out = {}
+    # variant "q" = the default trace (exact quotients); every other variant is a form of the product kernel
+    flags = 0 if os.environ.get("MIRO_AB_QUOTIENTS") == "1" else miro_amd.MR_MATH_PRODUCT
     for name in a.scenes.split(","):
         sc = miro_amd.Scene(0)
         scenes.populate(sc, name)
         sc.build(4)
-        fr = mframe.FrameRenderer(sc, name, a.w, a.h, spp=a.spp, flags=miro_amd.MR_MATH_PRODUCT)   # the variants are forms of the product kernel
+        fr = mframe.FrameRenderer(sc, name, a.w, a.h, spp=a.spp, flags=flags)
         fr.generate()
         fr.trace_primary()
         fr.make_shadow_rays()
@@ -54,7 +56,7 @@ def child(a):
         r[:, 4:7] = dd / dd.norm(dim=1, keepdim=True)
         r[:, 7] = 1e12
         hh = torch.empty((m, 4), device="cuda")
-        sc.trace_device(r, m, hh, miro_amd.MR_MATH_PRODUCT)
+        sc.trace_device(r, m, hh, flags)
         torch.cuda.synchronize()
         out[name + ".incoherent"] = checksum(hh)
         out[name + ".rays"] = [n_p, n_s, m]
@@ -64,7 +66,7 @@ def child(a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--child", action="store_true")
-    ap.add_argument("--variants", default="0,3,7,9")
+    ap.add_argument("--variants", default="0,3,7,9,11,q")
     ap.add_argument("--scenes", default="sponza,bunny,teapot")
     ap.add_argument("--w", type=int, default=1920)
     ap.add_argument("--h", type=int, default=1080)
@@ -75,7 +77,7 @@ def main():
         return child(a)
     results = {}
     for v in a.variants.split(","):
-        env = dict(os.environ, MIRO_TRACE_VARIANT=v)
+        env = dict(os.environ, MIRO_TRACE_VARIANT="11", MIRO_AB_QUOTIENTS="1") if v == "q" else dict(os.environ, MIRO_TRACE_VARIANT=v)
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--scenes", a.scenes, "--w", str(a.w),
                             "--h", str(a.h), "--spp", str(a.spp), "--incoherent", str(a.incoherent)],
                            env=env, capture_output=True, text=True)
