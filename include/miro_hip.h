@@ -100,7 +100,7 @@ enum {
                                       quotients (corner - o) / d (BVH.cpp:601-602), which the default reproduces bit for
                                       bit (one fma correction step per product: exactly the correctly rounded quotient
                                       for operands in the normal range; literal divisions otherwise).  A product differs
-                                      from the quotient by <= 2 ulp, which can flip a box comparison only on an exact
+                                      from the quotient by <= 3 ulp, which can flip a box comparison only on an exact
                                       tie (observed: 0 of 3e8 rays in normal use, 2 of 1.3e8 when tMax is set one ulp
                                       above a known hit); t / beta / gamma of a hit are the same bits either way.
                                       About 25 % faster */
