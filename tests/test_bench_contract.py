@@ -1,0 +1,35 @@
+"""bench.py's output contract: ONE JSON line on stdout with the driver's fields, the `roofline` object of the dominant
+kernel and the `cpu_baseline` object -- checked on a small frame so that the test takes seconds."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_contract_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--width", "320", "--height", "184", "--spp", "4", "--cpu-spp", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["unit"] == "Mrays/s" and j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1
+    assert j["higher_is_better"] is True and j["scaling"] == "strong" and j["vs_baseline"] is None and j["dtype"] == "f32"
+    assert j["value"] > 0 and j["ms_per_step"] > 0
+    assert "workload" in j["config"] and "model" not in j["config"]
+    rf = j["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
+    cb = j["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mrays/s" and cb["sample"]
+    # rays per step = primary + shadow of the frame actually traced
+    assert j["config"]["rays_per_step"] >= 320 * 184 * 4
