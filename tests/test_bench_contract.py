@@ -33,3 +33,27 @@ def test_bench_prints_one_contract_line():
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mrays/s" and cb["sample"]
     # rays per step = primary + shadow of the frame actually traced
     assert j["config"]["rays_per_step"] >= 320 * 184 * 4
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal():
+    """The N > 1 flow of bench.py -- rendezvous, interleaved row bands, per-rank frames, the pipelined framebuffer gather,
+    max-over-ranks timing, one line from rank 0 -- with two ranks sharing this box's GPU.  The collectives run over gloo
+    here (MIRO_DIST_BACKEND, host-staged gather): a rehearsal of the control flow, not a measurement."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MIRO_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "320", "--height", "184", "--spp", "4"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0
+    assert j["config"]["rays_per_step"] >= 320 * 184 * 4          # both ranks' rays are counted
+    assert "cpu_baseline" not in j                                # rank 0 times the CPU only at N = 1
