@@ -201,7 +201,9 @@ int orc_scene_add_obj(orc_scene *s, const char *path, const float *ctm_in)
     fseek(fp, 0, SEEK_SET);
 
     int ncap = nv > nf * 3 ? nv : nf * 3;                    /* :138 */
-    if (ncap < nn) ncap = nn;
+    /* the reference's array overflows when vn records and normal-less faces mix (nn + 3*faces can pass :138's
+     * size); give the restatement room for the worst case so such files behave as if the array were large enough */
+    if (ncap < nn + 3 * nf) ncap = nn + 3 * nf;
     v3 *normals = (v3 *)calloc((size_t)ncap + 1, sizeof(v3));
     v3 *verts = (v3 *)calloc((size_t)nv + 1, sizeof(v3));
     char *fix = (char *)calloc((size_t)ncap + 1, 1);
@@ -209,6 +211,7 @@ int orc_scene_add_obj(orc_scene *s, const char *path, const float *ctm_in)
     uint32_t *vidx = (uint32_t *)calloc((size_t)nf * 3 + 3, sizeof(uint32_t));
     uint32_t *nidx = (uint32_t *)calloc((size_t)nf * 3 + 3, sizeof(uint32_t));
     int ntris = 0, nvertices = 0, nnormals = 0;
+    int bad = 0;   /* an index the reference would chase out of bounds (undefined behaviour there): refuse the file */
 
     float nctm[16];
     mat_invert_transpose(ctm, nctm);                         /* :176-178 */
@@ -237,12 +240,14 @@ int orc_scene_add_obj(orc_scene *s, const char *path, const float *ctm_in)
             char *ss[3] = {s1, s2, s3};
             for (int k = 0; k < 3; k++) {
                 get_indices(ss[k], &v, &t, &n);
+                if (v < 1 || v > nvertices || n < 0 || n > ncap) { bad = 1; v = 1; n = 0; if (nvertices == 0) break; }
                 vidx[3 * ntris + k] = (uint32_t)(v - 1);
                 if (n) {
                     nidx[3 * ntris + k] = (uint32_t)(n - 1);
                     if (v >= 1 && v <= nv) ivec_push(&nbr[v - 1], n - 1);
                 }
             }
+            if (bad) break;
             if (!n) {                                        /* :252-281 (n of the LAST corner) */
                 v3 e1 = v3sub(verts[vidx[3 * ntris + 1]], verts[vidx[3 * ntris + 0]]);
                 v3 e2 = v3sub(verts[vidx[3 * ntris + 2]], verts[vidx[3 * ntris + 0]]);
@@ -261,6 +266,14 @@ int orc_scene_add_obj(orc_scene *s, const char *path, const float *ctm_in)
         }
     }
     fclose(fp);
+    /* a normal slot nobody ever wrote (neither a vn record nor a synthesised face normal): refused, as the product does */
+    for (int i = 0; i < 3 * ntris && !bad; i++)
+        if (nidx[i] >= (uint32_t)nnormals) bad = 1;
+    if (bad) {
+        for (int i = 0; i < nv; i++) free(nbr[i].d);
+        free(nbr); free(fix); free(normals); free(verts); free(vidx); free(nidx);
+        return -2;
+    }
 
     /* normal averaging (:287-308).  NB `Vector3 avg;` starts at (0,1,2) (Vector3.h:27). */
     for (int i = 0; i < nvertices; i++) {

@@ -172,3 +172,68 @@ def test_atrium_standin_costs_what_sponza_costs(oracle, tmp_path):
     _, (box2, tri2) = s.trace(sh, counters=True)
     Vb, Tb = (box + box2) / (2 * len(rays)), (tri + tri2) / (2 * len(rays))
     assert 0.75 * 51.2 <= Vb <= 1.1 * 51.2 and abs(Tb - 10.33) <= 0.10 * 10.33
+
+
+def _mutate(text, rng):
+    """One seeded mutation of an OBJ file's text: drop/duplicate/cut a line, flip a character, splice in a hostile
+    record."""
+    lines = text.split("\n")
+    hostile = ["f -1 -2 -3", "f 0 0 0", "f 1 2 99999", "f 1/1/77 2/1/1 3/1/1", "f 1 2", "f", "v", "v 1e39 nan inf",
+               "vn 0 0 0", "f 1//1 2//1 3", "v 1 2", "f 4294967297 2 3", "f a b c", "vn", "f 1/ 2/ 3/", "\x00", "v " + "9" * 120]
+    for _ in range(int(rng.integers(1, 4))):
+        k = int(rng.integers(0, 6))
+        i = int(rng.integers(0, len(lines)))
+        if k == 0:
+            del lines[i]
+        elif k == 1:
+            lines.insert(i, lines[i])
+        elif k == 2:
+            lines[i] = lines[i][: int(rng.integers(0, len(lines[i]) + 1))]
+        elif k == 3 and lines[i]:
+            j = int(rng.integers(0, len(lines[i])))
+            lines[i] = lines[i][:j] + chr(int(rng.integers(32, 127))) + lines[i][j + 1:]
+        else:
+            lines.insert(i, hostile[int(rng.integers(0, len(hostile)))])
+        if not lines:
+            lines = [""]
+    return "\n".join(lines)
+
+
+def test_loader_survives_mutated_files(oracle, miro, tmp_path):
+    """Seeded mutations of a small OBJ file: the product's loader must never crash or read out of bounds, must refuse
+    every file whose face indices the reference would chase outside its arrays (undefined behaviour in
+    `TriangleMesh::loadObj`, TriangleMeshLoad.cpp:187-282), and on every file it accepts must produce the oracle's
+    arrays bit for bit."""
+    base = ("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0.5\nv 2 0 1\nvt 0 0\nvt 1 0\nvn 0 0 2\nvn 0 3 0\n"
+            "f 1/1/1 2/2/1 3/1/2\nf 2//1 4//2 3//2\nf 2 5 4\nf 1/1 2/2 4/1\ng grp\nf 3/1/2 4/2/2 5\n")
+    rng = np.random.default_rng(168)
+    accepted = refused = 0
+    for i in range(300):
+        p = tmp_path / f"m{i}.obj"
+        p.write_bytes(_mutate(base, rng).encode("latin-1"))
+        a, b = oracle.Scene(), miro.Scene()
+        try:
+            na = a.add_obj(str(p))
+        except Exception:
+            na = None
+        try:
+            nb = b.add_obj(str(p))
+        except miro.MiroError as e:
+            assert e.status in (-1, -2)
+            nb = None
+        assert (na is None) == (nb is None), p.read_text(errors="replace")
+        if na is None:
+            refused += 1
+            continue
+        accepted += 1
+        assert na == nb
+        for x, y in zip(a.arrays(), b.arrays()):
+            # NaN sign/payload is whatever operand order the compiler chose for inf*0 (x86 propagates the first
+            # operand's): compare NaN positions, and bits everywhere else
+            assert x.shape == y.shape, p.read_text(errors="replace")
+            if x.dtype.kind == "f":
+                nx, ny = np.isnan(x), np.isnan(y)
+                assert np.array_equal(nx, ny) and np.array_equal(_bits(x)[~nx], _bits(y)[~ny]), p.read_text(errors="replace")
+            else:
+                assert np.array_equal(x, y), p.read_text(errors="replace")
+    assert accepted > 50 and refused > 20
