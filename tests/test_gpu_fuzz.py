@@ -135,3 +135,46 @@ def test_random_scene_bit_exact(oracle, miro, seed):
             rays = rays.copy()
             rays["tmax"] = np.where(hit, t, rays["tmax"]).astype(np.float32)
             rays["tmin"] = np.where(hit & (rng.random(len(rays)) < 0.1), want["t"], rays["tmin"]).astype(np.float32)
+
+
+def _same_bits_or_nan(got, want):
+    g, w = np.ascontiguousarray(got), np.ascontiguousarray(want)
+    gn, wn = np.isnan(g), np.isnan(w)
+    return np.array_equal(gn, wn) and np.array_equal(g.view(np.uint32)[~gn], w.view(np.uint32)[~wn])
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_scene_surfaces_and_shadow_rays(oracle, miro, seed):
+    """The callers either side of the traversal on the same scenes: HitInfo::P / ::N for triangles, spheres and planes
+    (Triangle.cpp:160-162, Sphere.cpp:58-66, Plane.cpp:42-45) and the Phong shadow rays (Phong.cpp:80-97), bit for bit
+    (NaNs, which zero-length normals produce, compared by position)."""
+    import torch
+    rng = np.random.default_rng(BASE + seed)
+    steps, leaf, extent = make_scene(rng)
+    a = replay(oracle.Scene(), steps, leaf)
+    b = replay(miro.Scene(), steps, leaf)
+    rays = make_rays(rng, oracle.RAY_DTYPE, steps, extent)
+    hits = a.trace(rays)
+    n = len(rays)
+    light = ((rng.random(3) - 0.5) * 4 * extent).astype(np.float32)
+    d_rays = torch.from_numpy(rays.view(np.float32).reshape(-1, 8).copy()).cuda()
+    d_hits = torch.from_numpy(hits.view(np.float32).reshape(-1, 4).copy()).cuda()
+    P = torch.empty((n, 3), dtype=torch.float32, device="cuda")
+    N = torch.empty((n, 3), dtype=torch.float32, device="cuda")
+    b.hit_attrs(d_hits, n, P, N, d_rays=d_rays)
+    Pw, Nw = a.hit_attrs(hits, rays)
+    hit = hits["prim"] != 0xFFFFFFFF
+    assert _same_bits_or_nan(P.cpu().numpy()[hit], Pw[hit])
+    assert _same_bits_or_nan(N.cpu().numpy()[hit], Nw[hit])
+    want, src_want = a.shadow_rays(rays, hits, light)
+    d_out = torch.empty((n, 8), dtype=torch.float32, device="cuda")
+    d_src = torch.empty(n, dtype=torch.int32, device="cuda")
+    d_cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    b.gen_shadow_rays(d_rays, d_hits, n, light, d_out, d_src, d_cnt)
+    k = int(d_cnt.item())
+    assert k == len(want)
+    src = d_src[:k].cpu().numpy().astype(np.int64)
+    order = np.argsort(src, kind="stable")
+    assert np.array_equal(src[order], src_want.astype(np.int64))
+    got = d_out[:k].cpu().numpy()[order]
+    assert _same_bits_or_nan(got, want.view(np.float32).reshape(-1, 8))
