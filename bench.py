@@ -112,7 +112,9 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64)
-    ap.add_argument("--band", type=int, default=8, help="rows per interleaved band when sharding the image")
+    ap.add_argument("--band", type=int, default=0,
+                    help="rows per interleaved band when sharding the image (0: the largest height <= 8 that gives every "
+                         "rank the same number of bands, else 8)")
     ap.add_argument("--fast", action="store_true", help="MR_MATH_FAST (not the parity mode; never the default)")
     ap.add_argument("--product", action="store_true",
                     help="MR_MATH_PRODUCT: slab distances as products with the rounded 1/d (about 25 %% faster; decisions can "
@@ -156,6 +158,8 @@ def main():
     t_build = time.perf_counter() - t_build
 
     W, H, spp = a.width, a.height, a.spp
+    if a.band <= 0:      # 1080 rows: 8 ranks -> 5 (27 bands each), 4 -> 6, 2 -> 6; bands of 8 would leave 17 vs 16
+        a.band = next((b for b in range(8, 0, -1) if H % b == 0 and (H // b) % world == 0), 8)
     bands = mframe.band_rows(H, a.band, rank, world)
     flags = miro_amd.MR_MATH_FAST if a.fast else (miro_amd.MR_MATH_PRODUCT if a.product else 0)
     stream = torch.cuda.current_stream()
