@@ -182,3 +182,36 @@ def test_random_scene_surfaces_and_shadow_rays(oracle, miro, seed):
     assert np.array_equal(src[order], src_want.astype(np.int64))
     got = d_out[:k].cpu().numpy()[order]
     assert _same_bits_or_nan(got, want.view(np.float32).reshape(-1, 8))
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_cameras_bit_exact(oracle, miro, seed):
+    """Camera::eyeRay (Camera.cpp:104-161) for random cameras -- grid and generic eye points, near-degenerate up
+    vectors, fov from 1 to 179 degrees, odd image sizes, row windows, 1-64 samples per pixel, jitter seeds."""
+    import torch
+    from miro_amd import binding
+    rng = np.random.default_rng(BASE + seed)
+    s = miro.Scene()
+    s.add_triangle([0, 0, 0, 1, 0, 0, 0, 1, 0], [0, 0, 1] * 3)
+    s.build(4)
+    for _ in range(6):
+        eye = (rng.integers(-8, 9, 3) * 0.5 if rng.random() < 0.5 else (rng.random(3) - 0.5) * 40).astype(np.float32)
+        look = (rng.integers(-8, 9, 3) * 0.5 if rng.random() < 0.5 else (rng.random(3) - 0.5) * 40).astype(np.float32)
+        if np.array_equal(eye, look):
+            look = look + np.float32(1.0)
+        up = rng.standard_normal(3).astype(np.float32) if rng.random() < 0.5 else np.asarray([0, 1, 0], np.float32)
+        if rng.random() < 0.2:                                   # nearly along the view direction
+            up = ((look - eye) + rng.standard_normal(3) * 1e-3).astype(np.float32)
+        fov = float(rng.choice([1.0, 20.0, 45.0, 55.0, 90.0, 120.0, 179.0]))
+        W, H = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+        spp = int(rng.choice([1, 2, 3, 16, 64]))
+        jitter = bool(rng.random() < 0.6)
+        sd = int(rng.integers(0, 2 ** 31))
+        y0 = int(rng.integers(0, H))
+        y1 = int(rng.integers(y0, H + 1))
+        want = oracle.eye_rays(oracle.make_camera(eye, look, up, fov), W, H, spp=spp, jitter=jitter, seed=sd, y0=y0, y1=y1)
+        d = torch.empty((max(1, (y1 - y0) * W * spp), 8), dtype=torch.float32, device="cuda")
+        n = s.gen_eye_rays(binding.make_camera(eye, look, up, fov), W, H, d, y0=y0, y1=y1, spp=spp, jitter=jitter, seed=sd)
+        assert n == len(want)
+        got = d[:n].cpu().numpy()
+        assert _same_bits_or_nan(got, want.view(np.float32).reshape(-1, 8)), (eye, look, up, fov, W, H, spp, jitter, sd, y0, y1)
