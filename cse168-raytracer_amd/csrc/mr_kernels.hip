@@ -551,12 +551,12 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(TraceParams p) {
 // ballots the idle lanes, retires their hits, and re-arms them with fresh rays by prefix-sum over the ballot
 // (wave64 active-ray compaction: lanes never wait for the slowest ray of a fixed group of 64).  Rays are handed
 // out from a wave-local pool of kPoolChunk consecutive indices so that the global counter sees one atomic per
-// chunk.  Per-ray work and results are those of trace_kernel.
+// chunk.  Per-ray work and results are those of trace_kernel: QUOT selects the default trace's exact quotients
+// (correction step for regular rays, the reference's divisions otherwise), !QUOT the MR_MATH_PRODUCT arithmetic.
 // ---------------------------------------------------------------------------------------------------
 constexpr unsigned long long kPoolChunk = 1024;
-constexpr int kPersistentSafeSlab = 1;    // same slab arithmetic as the default kernel (bit-identical results)
 
-template <bool EXACT, bool ANY, int REFILL_MIN>
+template <bool EXACT, bool ANY, bool QUOT, int REFILL_MIN>
 __global__ __launch_bounds__(kTraceBlock) void trace_persistent_kernel(TraceParams p, unsigned long long *next_ray) {
     extern __shared__ int s_stack[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -604,11 +604,11 @@ __global__ __launch_bounds__(kTraceBlock) void trace_persistent_kernel(TracePara
                     L.best_t = tmax0; L.best_b = 0.0f; L.best_g = 0.0f; L.best_pos = -1;
                     stack_reset(L, s_stack, tid);
                     float mn = -kInf, mx = kInf;
-                    slab_axis<false>(p.root_lo[0], p.root_hi[0], r.ox, r.dx, r.ix, mn, mx);
-                    slab_axis<false>(p.root_lo[1], p.root_hi[1], r.oy, r.dy, r.iy, mn, mx);
-                    slab_axis<false>(p.root_lo[2], p.root_hi[2], r.oz, r.dz, r.iz, mn, mx);
+                    slab_axis<QUOT>(p.root_lo[0], p.root_hi[0], r.ox, r.dx, r.ix, mn, mx);
+                    slab_axis<QUOT>(p.root_lo[1], p.root_hi[1], r.oy, r.dy, r.iy, mn, mx);
+                    slab_axis<QUOT>(p.root_lo[2], p.root_hi[2], r.oz, r.dz, r.iz, mn, mx);
                     L.cur = !((mn > mx) || (mn > tmax0) || (mx < r.tmin)) ? p.root_ref : kDone;
-                    safe_lane = lane_is_nan_free(r);
+                    safe_lane = QUOT ? lane_is_regular(r) : lane_is_nan_free(r);
                 }
                 const unsigned long long adv = pool_next + (unsigned)n_idle;
                 pool_next = adv < pool_end ? adv : pool_end;
@@ -626,9 +626,9 @@ __global__ __launch_bounds__(kTraceBlock) void trace_persistent_kernel(TracePara
             continue;
         }
         if (__all(safe_lane || !L.have())) {
-            while (L.cur >= 0) node_step<EXACT, false, kPersistentSafeSlab, true>(p, r, L, s_stack, tid, st);
+            while (L.cur >= 0) node_step<EXACT, false, QUOT ? 4 : 1, true>(p, r, L, s_stack, tid, st);
         } else {
-            while (L.cur >= 0) node_step<EXACT, false, 0>(p, r, L, s_stack, tid, st);
+            while (L.cur >= 0) node_step<EXACT, false, QUOT ? 3 : 0, QUOT>(p, r, L, s_stack, tid, st);
         }
         if (L.have()) leaf_step<EXACT, ANY, false, true>(p, r, L, s_stack, tid, st);
     }
@@ -815,11 +815,11 @@ static int trace_variant() {
     return v;
 }
 
-template <bool EXACT, bool ANY, int REFILL_MIN>
+template <bool EXACT, bool ANY, bool QUOT, int REFILL_MIN>
 static mr_status launch_persistent(const TraceParams &p, hipStream_t stream) {
     const size_t lds = (size_t)p.stack_depth * kTraceBlock * sizeof(int);
     if (lds > 160 * 1024) return fail(MR_ERR_INVALID, "traversal stack of depth %d does not fit in LDS", p.stack_depth);
-    auto kern = &trace_persistent_kernel<EXACT, ANY, REFILL_MIN>;
+    auto kern = &trace_persistent_kernel<EXACT, ANY, QUOT, REFILL_MIN>;
     if (lds > 64 * 1024)
         MR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int dev = 0, cus = 256, per_cu = 1;
@@ -845,8 +845,8 @@ static mr_status launch_exact(const TraceParams &p, hipStream_t stream) {
         case 3: return launch_trace_t<true, ANY, false, 3>(p, stream);
         case 7: return launch_trace_t<true, ANY, false, 7>(p, stream);
         case 9: return launch_trace_t<true, ANY, false, 9>(p, stream);
-        case 16: return launch_persistent<true, ANY, 1>(p, stream);
-        case 17: return launch_persistent<true, ANY, 16>(p, stream);
+        case 16: return launch_persistent<true, ANY, false, 1>(p, stream);
+        case 17: return launch_persistent<true, ANY, false, 16>(p, stream);
         default: return launch_trace_t<true, ANY, false, 11>(p, stream);
     }
 }
@@ -868,7 +868,10 @@ mr_status launch_trace(const TraceParams &p, uint32_t flags, hipStream_t stream)
     }
     // MR_MATH_FAST: lean fma slabs + fmaf/rcp triangle test, with the same scalar-cache path as the exact kernels (VAR 15)
     if (fast) return any ? launch_trace_t<false, true, false, 15>(p, stream) : launch_trace_t<false, false, false, 15>(p, stream);
-    if (flags & MR_TRACE_PERSISTENT) return any ? launch_persistent<true, true, 16>(p, stream) : launch_persistent<true, false, 16>(p, stream);
+    if (flags & MR_TRACE_PERSISTENT) {
+        if (product) return any ? launch_persistent<true, true, false, 16>(p, stream) : launch_persistent<true, false, false, 16>(p, stream);
+        return any ? launch_persistent<true, true, true, 16>(p, stream) : launch_persistent<true, false, true, 16>(p, stream);
+    }
     // MR_MATH_PRODUCT: slab distances as products with the rounded 1/d (and its development variants)
     if (product) return any ? launch_exact<true>(p, stream) : launch_exact<false>(p, stream);
     // default: the reference's quotients by the correction step, while-while, scalar path (VAR 16 | 2 | 8)

@@ -94,8 +94,9 @@ enum {
                                       of Triangle.cpp:150-156 and is what parity and the bench are quoted on */
     MR_COUNT_STATS    = 1u << 4,   /* accumulate -DSTATS counters (BVH.cpp:461,496,632,643) */
     MR_TRACE_PERSISTENT = 1u << 5, /* incoherent batches: resident waves pull rays from a counter and re-arm idle
-                                      lanes by wave64 ballot + prefix sum (implies MR_MATH_PRODUCT; on par with the
-                                      one-shot kernel on random rays, slower on coherent camera rays -- off by default;
+                                      lanes by wave64 ballot + prefix sum.  Same arithmetic and hit records as the
+                                      one-shot kernel (exact quotients, or products with MR_MATH_PRODUCT); on par with
+                                      it on random rays, slower on coherent camera rays -- off by default;
                                       triangle scenes only: ignored, i.e. the default kernel runs, when the scene holds
                                       spheres or planes, and under MR_COUNT_STATS / MR_MATH_FAST) */
     MR_MATH_PRODUCT   = 1u << 6    /* slab distances as products (corner - o) * RN(1/d) instead of the reference's

@@ -124,10 +124,10 @@ def test_random_scene_bit_exact(oracle, miro, seed):
         prod = b.trace(r, flags=miro.MR_MATH_PRODUCT)
         diff = int((prod.view(np.uint32).reshape(-1, 4) != want.view(np.uint32).reshape(-1, 4)).any(1).sum())
         assert diff <= len(rays) // 100, diff
-        # the persistent kernel runs the product form on triangle scenes and must equal the product launch, whatever
-        # that returned; with spheres or planes in the scene the flag is a no-op and the default kernel answers
-        only_triangles = all(st[0] == "mesh" for st in steps)
-        assert_hits_bit_exact(b.trace(r, flags=miro.MR_TRACE_PERSISTENT), prod if only_triangles else want)
+        # the persistent kernel computes what the one-shot kernel computes, in either arithmetic (with spheres or
+        # planes in the scene the flag is a no-op and the one-shot kernels answer)
+        assert_hits_bit_exact(b.trace(r, flags=miro.MR_TRACE_PERSISTENT), want)
+        assert_hits_bit_exact(b.trace(r, flags=miro.MR_TRACE_PERSISTENT | miro.MR_MATH_PRODUCT), prod)
         if diff and os.environ.get("MIRO_FUZZ_VERBOSE"):
             print(f"seed {seed} round {rnd}: product form differs on {diff} of {len(rays)} rays")
         if rnd == 0:
