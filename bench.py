@@ -193,6 +193,11 @@ def main():
         if gather is not None:
             gather.start()
 
+    if gather is not None:
+        # RCCL sets up its point-to-point channels at the first send/recv between a pair of ranks: do that here, so
+        # that a run with --warmup 0 does not time connection set-up (the buffer holds no frame yet; nothing reads it)
+        gather.start()
+        gather.wait()
     for _ in range(a.warmup):
         one_step()
     if gather is not None:
