@@ -44,6 +44,11 @@ void release_device(mr_scene *s) {
     (void)hipFree(s->d_stage_rays); (void)hipFree(s->d_stage_hits);
     s->d_stage_rays = s->d_stage_hits = nullptr;
     s->stage_cap = 0;
+    for (void *e : s->stage_events) (void)hipEventDestroy(static_cast<hipEvent_t>(e));
+    s->stage_events.clear();
+    if (s->copy_in) (void)hipStreamDestroy(static_cast<hipStream_t>(s->copy_in));
+    if (s->copy_out) (void)hipStreamDestroy(static_cast<hipStream_t>(s->copy_out));
+    s->copy_in = s->copy_out = nullptr;
     (void)hipFree(s->d_occluded);
     s->d_occluded = nullptr;
     s->occluded_cap = 0;
@@ -197,6 +202,26 @@ mr_status ensure_stage(mr_scene *s, uint64_t n) {
     MR_HIP_CHECK(hipMalloc(&s->d_stage_rays, n * sizeof(mr_ray)));
     MR_HIP_CHECK(hipMalloc(&s->d_stage_hits, n * sizeof(mr_hit)));
     s->stage_cap = n;
+    return MR_OK;
+}
+
+// copy streams and 2 events per chunk for the pipelined host-pointer trace
+mr_status ensure_copy_pipeline(mr_scene *s, uint64_t n_chunks) {
+    if (!s->copy_in) {
+        hipStream_t a = nullptr;
+        MR_HIP_CHECK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+        s->copy_in = a;
+    }
+    if (!s->copy_out) {
+        hipStream_t b = nullptr;
+        MR_HIP_CHECK(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
+        s->copy_out = b;
+    }
+    while (s->stage_events.size() < 2 * n_chunks) {
+        hipEvent_t e = nullptr;
+        MR_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        s->stage_events.push_back(e);
+    }
     return MR_OK;
 }
 
@@ -414,6 +439,33 @@ mr_status mr_trace(mr_scene *s, const mr_ray *rays, uint64_t n, mr_hit *hits, ui
     p.rays = d_rays; p.hits = d_hits; p.n = n; p.n_dev = nullptr; p.stats = s->d_stats;
     p.planes = s->dev.planes; p.n_planes = s->dev.n_planes; p.n_spheres = s->dev.n_spheres;
     p.work_counter = s->d_work_counters + (s->next_counter.fetch_add(1) % kWorkCounters);
+    if (staged.owns_lock() && n > kStageChunk) {
+        // host buffers, large batch: chunk k+1 uploads and chunk k-1 downloads while chunk k is traced (full overlap when
+        // the caller's buffers are pinned -- mr_host_alloc --, since only then are the copies asynchronous to this thread)
+        const uint64_t n_chunks = (n + kStageChunk - 1) / kStageChunk;
+        if ((st = ensure_copy_pipeline(s, n_chunks)) != MR_OK) return st;
+        // (alternating the uploads between two copy streams changes nothing: one queue already fills the link, 27 GB/s up)
+        hipStream_t in = static_cast<hipStream_t>(s->copy_in), out = static_cast<hipStream_t>(s->copy_out);
+        for (uint64_t k = 0; k < n_chunks; k++) {
+            const uint64_t off = k * kStageChunk, m = n - off < kStageChunk ? n - off : kStageChunk;
+            hipEvent_t up = static_cast<hipEvent_t>(s->stage_events[2 * k]), done = static_cast<hipEvent_t>(s->stage_events[2 * k + 1]);
+            if (!rays_dev) {
+                MR_HIP_CHECK(hipMemcpyAsync(static_cast<mr_ray *>(s->d_stage_rays) + off, rays + off, m * sizeof(mr_ray), hipMemcpyHostToDevice, in));
+                MR_HIP_CHECK(hipEventRecord(up, in));
+                MR_HIP_CHECK(hipStreamWaitEvent(stream, up, 0));
+            }
+            p.rays = d_rays + off; p.hits = d_hits + off; p.n = m;
+            if ((st = launch_trace(p, flags, stream)) != MR_OK) return st;
+            if (!hits_dev) {
+                MR_HIP_CHECK(hipEventRecord(done, stream));
+                MR_HIP_CHECK(hipStreamWaitEvent(out, done, 0));
+                MR_HIP_CHECK(hipMemcpyAsync(hits + off, d_hits + off, m * sizeof(mr_hit), hipMemcpyDeviceToHost, out));
+            }
+        }
+        if (!hits_dev) MR_HIP_CHECK(hipStreamSynchronize(out));
+        MR_HIP_CHECK(hipStreamSynchronize(stream));
+        return MR_OK;
+    }
     if ((st = launch_trace(p, flags, stream)) != MR_OK) return st;
     if (!hits_dev) {
         MR_HIP_CHECK(hipMemcpyAsync(hits, d_hits, n * sizeof(mr_hit), hipMemcpyDeviceToHost, stream));
@@ -421,6 +473,19 @@ mr_status mr_trace(mr_scene *s, const mr_ray *rays, uint64_t n, mr_hit *hits, ui
     } else if (!rays_dev) {
         MR_HIP_CHECK(hipStreamSynchronize(stream));   // the staged host rays may be reused by the caller
     }
+    return MR_OK;
+}
+
+mr_status mr_host_alloc(void **ptr, uint64_t bytes) {
+    if (!ptr) return fail(MR_ERR_INVALID, "ptr is NULL");
+    *ptr = nullptr;
+    if (bytes == 0) return MR_OK;
+    MR_HIP_CHECK(hipHostMalloc(ptr, bytes, hipHostMallocPortable));
+    return MR_OK;
+}
+
+mr_status mr_host_free(void *ptr) {
+    if (ptr) MR_HIP_CHECK(hipHostFree(ptr));
     return MR_OK;
 }
 

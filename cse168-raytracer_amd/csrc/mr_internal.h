@@ -85,6 +85,7 @@ mr_status build_reference_tree(const HostMesh &mesh, uint32_t leaf_size, HostTre
 constexpr int kLeafCountBits = 4;
 constexpr int kLeafCountMask = 15;
 constexpr uint32_t kWorkCounters = 64;   // launches in flight on different streams each get their own counter
+constexpr uint64_t kStageChunk = 1ull << 20;   // rays per chunk of a pipelined host-pointer trace (32 MiB up, 16 MiB down)
 
 struct DeviceScene {
     float4   *nodes = nullptr;         // 4 * n_inner
@@ -183,6 +184,10 @@ struct mr_scene {
     void *d_stage_rays = nullptr, *d_stage_hits = nullptr;
     uint64_t stage_cap = 0;
     std::mutex stage_mutex;
+    // large host-pointer traces are cut into chunks: upload of chunk k+1, kernel of chunk k and download of chunk k-1
+    // overlap on these copy streams (events order them against the caller's stream)
+    void *copy_in = nullptr, *copy_out = nullptr;   // hipStream_t
+    std::vector<void *> stage_events;               // hipEvent_t, grow-only
     // grow-only per-primary-ray occlusion flags for mr_shade_direct
     uint8_t *d_occluded = nullptr;
     uint64_t occluded_cap = 0;

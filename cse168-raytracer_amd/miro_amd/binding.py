@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "mr_scene_create", "mr_scene_destroy", "mr_scene_add_mesh", "mr_scene_add_obj", "mr_scene_add_triangle",
     "mr_scene_add_sphere", "mr_scene_add_plane",
     "mr_bvh_build", "mr_scene_get_info", "mr_scene_get_mesh", "mr_scene_export_tree",
-    "mr_trace", "mr_trace_indirect", "mr_trace_get_stats", "mr_gen_eye_rays", "mr_gen_shadow_rays", "mr_hit_attrs",
+    "mr_trace", "mr_host_alloc", "mr_host_free", "mr_trace_indirect", "mr_trace_get_stats", "mr_gen_eye_rays", "mr_gen_shadow_rays", "mr_hit_attrs",
     "mr_shade_direct", "mr_tonemap",
     "mr_scene_set_materials", "mr_shade_accumulate", "mr_gen_secondary_rays",
     "mr_photon_map_create", "mr_photon_map_destroy", "mr_photon_map_store", "mr_photon_map_scale",
@@ -122,6 +122,8 @@ def load_library(path=None):
     L.mr_scene_export_tree.argtypes = [vp, f32p, C.POINTER(C.c_int32), u32p]
     L.mr_trace.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp]
     L.mr_trace_indirect.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_uint32, vp]
+    L.mr_host_alloc.argtypes = [C.POINTER(vp), C.c_uint64]
+    L.mr_host_free.argtypes = [vp]
     L.mr_trace_get_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]
     L.mr_gen_eye_rays.argtypes = [vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                   C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
@@ -165,6 +167,30 @@ def _f32p(a):
 
 def _u32p(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+class PinnedArray:
+    """A numpy array in page-locked host memory (mr_host_alloc); keep the object alive while `.array` is in use."""
+
+    def __init__(self, n, dtype):
+        self.L = lib()
+        dtype = np.dtype(dtype)
+        self.ptr = C.c_void_p()
+        _check(self.L.mr_host_alloc(C.byref(self.ptr), max(1, n) * dtype.itemsize))
+        buf = (C.c_char * (n * dtype.itemsize)).from_address(self.ptr.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=n)
+
+    def close(self):
+        if self.ptr is not None and self.ptr.value:
+            self.array = None
+            self.L.mr_host_free(self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def make_camera(eye, lookat, up, fov_deg):
@@ -276,10 +302,12 @@ class Scene:
         return corners, meta, prims[:i.n_triangles]
 
     # ---- Scene::trace, batched
-    def trace(self, rays, flags=0):
-        """Host numpy rays (RAY_DTYPE) -> host numpy hits (HIT_DTYPE)."""
+    def trace(self, rays, flags=0, hits=None):
+        """Host numpy rays (RAY_DTYPE) -> host numpy hits (HIT_DTYPE); `hits` may be a caller's (e.g. pinned) array."""
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
-        hits = np.empty(len(rays), HIT_DTYPE)
+        if hits is None:
+            hits = np.empty(len(rays), HIT_DTYPE)
+        assert hits.dtype == HIT_DTYPE and len(hits) == len(rays) and hits.flags["C_CONTIGUOUS"]
         flags &= ~(MR_RAYS_ON_DEVICE | MR_HITS_ON_DEVICE)
         _check(self.L.mr_trace(self.h, rays.ctypes.data, len(rays), hits.ctypes.data, flags, None))
         return hits

@@ -142,14 +142,21 @@ mr_status mr_scene_get_mesh(const mr_scene *scene, mr_mesh_desc *out);
 mr_status mr_scene_export_tree(const mr_scene *scene, float *corners6, int32_t *meta3, uint32_t *leaf_prims);
 
 /* ---- Scene::trace, batched (Scene.cpp:214-268 -> BVH.cpp:438-658 -> Triangle.cpp:136-169) ------- */
-/* stream: a hipStream_t (NULL = default stream).  Host buffers are staged synchronously;
- * with both buffers on the device the call only enqueues work on `stream`.
+/* stream: a hipStream_t (NULL = default stream).  Host buffers are staged and the call returns when the hits are
+ * in `hits`; batches above 2^20 rays are cut into chunks whose upload, trace and download overlap (fully so when the
+ * buffers are pinned, see mr_host_alloc; pageable memory is staged by the HIP runtime on the calling thread).
+ * With both buffers on the device the call only enqueues work on `stream`.
  * Threads: a built scene is immutable and mr_trace / mr_trace_indirect may be called on it from several host
  * threads at once, like the reference's const Scene::trace from its OpenMP workers (Scene.cpp:112-115); calls
  * with host buffers take turns on the scene's staging buffers.  mr_shade_direct and mr_shade_accumulate keep
  * per-scene scratch (occlusion flags, light scale): one such call in flight per scene. */
 mr_status mr_trace(mr_scene *scene, const mr_ray *rays, uint64_t n_rays, mr_hit *hits,
                    uint32_t flags, void *stream);
+/* Page-locked host memory for ray / hit buffers handed to mr_trace (the reference's callers keep Ray and HitInfo in
+ * ordinary `new`-ed memory, Scene.cpp:117-140; pinned buffers let the copies run at PCIe speed and overlap the trace).
+ * Usable from any device; free with mr_host_free (NULL is a no-op). */
+mr_status mr_host_alloc(void **ptr, uint64_t bytes);
+mr_status mr_host_free(void *ptr);
 /* Same, for a batch whose size was produced on the device (the compacted shadow batch of
  * mr_gen_shadow_rays): traces min(*d_count, max_rays) rays without a host round trip.  All pointers are
  * device pointers; MR_RAYS_ON_DEVICE / MR_HITS_ON_DEVICE are implied. */

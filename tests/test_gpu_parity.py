@@ -515,3 +515,39 @@ def test_degenerate_triangles_and_coplanar_rays(oracle, miro, torch_cuda):
     b.stats()
     b.trace(rays.view(miro.RAY_DTYPE), flags=miro.MR_COUNT_STATS)
     assert b.stats() == ctr
+
+
+def test_large_host_batches_are_pipelined_in_chunks(oracle, miro, torch_cuda):
+    """Host-pointer batches above 2^20 rays go through the chunked upload / trace / download pipeline: same hit
+    records as the device-buffer path, from pageable and from page-locked (mr_host_alloc) buffers, ragged last chunk,
+    counters accumulated over the chunks, persistent kernel per chunk."""
+    torch = torch_cuda
+    a, b = both(oracle, miro, "teapot")
+    lo, hi = scene_box(a)
+    n = 2 * (1 << 20) + 12345
+    rays = random_rays(miro.RAY_DTYPE, n, np.maximum(lo, -20), np.minimum(hi, 20), seed=77)
+    d_rays = torch.from_numpy(rays.view(np.float32).reshape(-1, 8).copy()).cuda()
+    d_hits = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    b.trace_device(d_rays, n, d_hits)
+    torch.cuda.synchronize()
+    want = d_hits.cpu().numpy().view(miro.HIT_DTYPE).reshape(-1)
+    sub = np.arange(0, n, 97)
+    assert_hits_bit_exact(want[sub], a.trace(rays[sub].view(oracle.RAY_DTYPE)).view(miro.HIT_DTYPE))
+    assert_hits_bit_exact(b.trace(rays), want)
+    pr, ph = miro.PinnedArray(n, miro.RAY_DTYPE), miro.PinnedArray(n, miro.HIT_DTYPE)
+    try:
+        pr.array[:] = rays
+        ph.array.view(np.uint32)[:] = 0xDEADBEEF
+        b.trace(pr.array, hits=ph.array)
+        assert_hits_bit_exact(ph.array, want)
+        ph.array.view(np.uint32)[:] = 0xDEADBEEF
+        b.trace(pr.array, flags=miro.MR_TRACE_PERSISTENT, hits=ph.array)
+        assert_hits_bit_exact(ph.array, want)
+        b.stats()
+        b.trace_device(d_rays, n, d_hits, flags=miro.MR_COUNT_STATS)
+        torch.cuda.synchronize()
+        ctr = b.stats()
+        assert_hits_bit_exact(b.trace(pr.array, flags=miro.MR_COUNT_STATS), want)
+        assert b.stats() == ctr
+    finally:
+        pr.close(); ph.close()
