@@ -8,6 +8,7 @@
 #include <new>
 
 #include "mr_internal.h"
+#include "mr_tile.h"
 
 namespace mr {
 
@@ -532,7 +533,30 @@ mr_status mr_gen_eye_rays(mr_scene *s, const mr_camera *cam, uint32_t W, uint32_
     if (W == 0 || H == 0 || spp == 0 || y1 < y0 || y1 > H) return fail(MR_ERR_INVALID, "bad image window");
     if (reinterpret_cast<uintptr_t>(d_rays) & 15) return fail(MR_ERR_INVALID, "d_rays must be 16-byte aligned");
     MR_HIP_CHECK(hipSetDevice(s->device));
-    return launch_eye_rays(*cam, W, H, y0, y1, spp, jitter, seed, d_rays, static_cast<hipStream_t>(stream));
+    return launch_eye_rays(*cam, W, H, y0, y1, spp, jitter, seed, false, d_rays, static_cast<hipStream_t>(stream));
+}
+
+mr_status mr_gen_eye_rays_tiled(mr_scene *s, const mr_camera *cam, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,
+                                uint32_t spp, uint32_t jitter, uint32_t seed, mr_ray *d_rays, void *stream) {
+    if (!s || !cam || !d_rays) return fail(MR_ERR_INVALID, "NULL argument");
+    if (W == 0 || H == 0 || spp == 0 || y1 < y0 || y1 > H) return fail(MR_ERR_INVALID, "bad image window");
+    if ((uint64_t)W * (y1 - y0) > 0xFFFFFFFFull) return fail(MR_ERR_INVALID, "window of more than 2^32-1 pixels");
+    if (reinterpret_cast<uintptr_t>(d_rays) & 15) return fail(MR_ERR_INVALID, "d_rays must be 16-byte aligned");
+    MR_HIP_CHECK(hipSetDevice(s->device));
+    return launch_eye_rays(*cam, W, H, y0, y1, spp, jitter, seed, true, d_rays, static_cast<hipStream_t>(stream));
+}
+
+mr_status mr_tile_pixel_map(uint32_t W, uint32_t rows, uint32_t spp, uint32_t *pixel_of_slot) {
+    if (!pixel_of_slot && (uint64_t)W * rows) return fail(MR_ERR_INVALID, "pixel_of_slot is NULL");
+    if ((uint64_t)W * rows > 0xFFFFFFFFull) return fail(MR_ERR_INVALID, "window of more than 2^32-1 pixels");
+    const mr::TileShape t = mr::tile_shape(spp);
+    const uint32_t n = W * rows;
+    for (uint32_t p = 0; p < n; p++) {
+        uint32_t x, yl;
+        mr::tile_decode(p, W, rows, t, x, yl);
+        pixel_of_slot[p] = yl * W + x;
+    }
+    return MR_OK;
 }
 
 mr_status mr_gen_shadow_rays(mr_scene *s, const mr_ray *d_rays, const mr_hit *d_hits, uint64_t n, const float light[3],

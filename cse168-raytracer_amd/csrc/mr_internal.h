@@ -128,7 +128,7 @@ struct TraceParams {
 
 mr_status launch_trace(const TraceParams &p, uint32_t flags, hipStream_t stream);
 mr_status launch_eye_rays(const mr_camera &cam, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,
-                          uint32_t spp, uint32_t jitter, uint32_t seed, mr_ray *d_rays, hipStream_t stream);
+                          uint32_t spp, uint32_t jitter, uint32_t seed, bool tiled, mr_ray *d_rays, hipStream_t stream);
 mr_status launch_shadow_rays(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits,
                              unsigned long long n, const float light[3], mr_ray *d_out, uint32_t *d_src,
                              unsigned long long *d_count, hipStream_t stream);

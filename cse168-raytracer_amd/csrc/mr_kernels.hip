@@ -20,6 +20,7 @@
 
 #include "mr_internal.h"
 #include "mr_surface.h"
+#include "mr_tile.h"
 
 namespace mr {
 namespace {
@@ -642,6 +643,8 @@ struct EyeFrame {
     float eye[3], u[3], v[3], w[3];
     float left, right, bottom, top;
     uint32_t W, H, y0, spp, jitter, hbase;
+    uint32_t tiled, rows;        // tiled: ray order of mr_tile.h inside the window of `rows` rows
+    TileShape tile;
     unsigned long long n;
 };
 
@@ -657,7 +660,12 @@ __global__ __launch_bounds__(kBlock) void eye_rays_kernel(EyeFrame f, mr_ray *ra
     for (unsigned long long k = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; k < f.n; k += stride) {
         const unsigned long long pix_local = k / f.spp;
         const uint32_t sm = (uint32_t)(k - pix_local * f.spp);
-        const uint32_t y = f.y0 + (uint32_t)(pix_local / f.W), x = (uint32_t)(pix_local % f.W);
+        uint32_t y = f.y0 + (uint32_t)(pix_local / f.W), x = (uint32_t)(pix_local % f.W);
+        if (f.tiled) {
+            uint32_t yl;
+            tile_decode((uint32_t)pix_local, f.W, f.rows, f.tile, x, yl);
+            y = f.y0 + yl;
+        }
         float dx = 0.5f, dy = 0.5f;
         if (f.jitter) {
             const uint32_t pix = y * f.W + x;
@@ -879,7 +887,7 @@ mr_status launch_trace(const TraceParams &p, uint32_t flags, hipStream_t stream)
 }
 
 mr_status launch_eye_rays(const mr_camera &cam, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,
-                          uint32_t spp, uint32_t jitter, uint32_t seed, mr_ray *d_rays, hipStream_t stream) {
+                          uint32_t spp, uint32_t jitter, uint32_t seed, bool tiled, mr_ray *d_rays, hipStream_t stream) {
     // camera frame on the host, in the reference's order of operations (Camera.h:79-110, Camera.cpp:113-124)
     auto unit3 = [](float *a) {
         const float len = sqrtf((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
@@ -906,6 +914,9 @@ mr_status launch_eye_rays(const mr_camera &cam, uint32_t W, uint32_t H, uint32_t
     f.right = aspect * f.top; f.bottom = -f.top; f.left = -f.right;
     f.eye[0] = cam.eye[0]; f.eye[1] = cam.eye[1]; f.eye[2] = cam.eye[2];
     f.W = W; f.H = H; f.y0 = y0; f.spp = spp; f.jitter = jitter;
+    f.tile = tile_shape(spp);
+    f.rows = y1 - y0;
+    f.tiled = tiled && (f.tile.th > 1 || f.tile.tw > 1) ? 1u : 0u;
     {   // host copy of pcg_hash
         uint32_t state = seed * 747796405u + 2891336453u;
         uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;

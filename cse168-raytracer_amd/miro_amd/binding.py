@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "mr_scene_create", "mr_scene_destroy", "mr_scene_add_mesh", "mr_scene_add_obj", "mr_scene_add_triangle",
     "mr_scene_add_sphere", "mr_scene_add_plane",
     "mr_bvh_build", "mr_scene_get_info", "mr_scene_get_mesh", "mr_scene_export_tree",
-    "mr_trace", "mr_host_alloc", "mr_host_free", "mr_trace_indirect", "mr_trace_get_stats", "mr_gen_eye_rays", "mr_gen_shadow_rays", "mr_hit_attrs",
+    "mr_trace", "mr_host_alloc", "mr_host_free", "mr_trace_indirect", "mr_trace_get_stats", "mr_gen_eye_rays", "mr_gen_eye_rays_tiled", "mr_tile_pixel_map", "mr_gen_shadow_rays", "mr_hit_attrs",
     "mr_shade_direct", "mr_tonemap",
     "mr_scene_set_materials", "mr_shade_accumulate", "mr_gen_secondary_rays",
     "mr_photon_map_create", "mr_photon_map_destroy", "mr_photon_map_store", "mr_photon_map_scale",
@@ -127,6 +127,8 @@ def load_library(path=None):
     L.mr_trace_get_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]
     L.mr_gen_eye_rays.argtypes = [vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                   C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
+    L.mr_gen_eye_rays_tiled.argtypes = L.mr_gen_eye_rays.argtypes
+    L.mr_tile_pixel_map.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, u32p]
     L.mr_gen_shadow_rays.argtypes = [vp, vp, vp, C.c_uint64, f32p, vp, vp, vp, vp]
     L.mr_hit_attrs.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, vp]
     L.mr_scene_add_sphere.argtypes = [vp, f32p, C.c_float, u32p]
@@ -191,6 +193,13 @@ class PinnedArray:
             self.close()
         except Exception:
             pass
+
+
+def tile_pixel_map(W, rows, spp):
+    """pixel_of_slot[p] = local row-major pixel index of slot p of a tiled window (mr_tile_pixel_map), uint32 numpy."""
+    out = np.empty(W * rows, np.uint32)
+    _check(lib().mr_tile_pixel_map(W, rows, spp, _u32p(out)))
+    return out
 
 
 def make_camera(eye, lookat, up, fov_deg):
@@ -329,10 +338,11 @@ class Scene:
         return a.value, b.value
 
     # ---- callers on the device
-    def gen_eye_rays(self, cam, W, H, d_rays, y0=0, y1=None, spp=1, jitter=False, seed=168, stream=None):
+    def gen_eye_rays(self, cam, W, H, d_rays, y0=0, y1=None, spp=1, jitter=False, seed=168, stream=None, tiled=False):
+        """Camera::eyeRay for rows [y0, y1); tiled=True: the tiled order of mr_gen_eye_rays_tiled (see tile_pixel_map)."""
         y1 = H if y1 is None else y1
-        _check(self.L.mr_gen_eye_rays(self.h, C.byref(cam), W, H, y0, y1, spp, 1 if jitter else 0, seed,
-                                      d_rays.data_ptr(), _stream_ptr(stream)))
+        fn = self.L.mr_gen_eye_rays_tiled if tiled else self.L.mr_gen_eye_rays
+        _check(fn(self.h, C.byref(cam), W, H, y0, y1, spp, 1 if jitter else 0, seed, d_rays.data_ptr(), _stream_ptr(stream)))
         return (y1 - y0) * W * spp
 
     def gen_shadow_rays(self, d_rays, d_hits, n, light, d_out, d_src, d_count, stream=None):

@@ -109,7 +109,8 @@ def gather_framebuffer(local_rgb, H, W, band, rank, world, group=None, dst=0):
 class FrameRenderer:
     """All device buffers of one rank's share of a frame, resident for the lifetime of the object."""
 
-    def __init__(self, scene, desc, W, H, spp=1, bands=None, jitter=None, seed=168, flags=0, device=None, rgb=None):
+    def __init__(self, scene, desc, W, H, spp=1, bands=None, jitter=None, seed=168, flags=0, device=None, rgb=None,
+                 tiled=None):
         if isinstance(desc, str):
             desc = scenes.SCENES[desc]
         self.scene, self.desc, self.W, self.H, self.spp = scene, desc, W, H, spp
@@ -131,10 +132,28 @@ class FrameRenderer:
         # rgb: an external [n_pixels, 3] buffer to shade into (FrameGather.local on a multi-GPU node)
         self.d_rgb = torch.zeros((max(self.n_pixels, 1), 3), **f32) if rgb is None else rgb
         self.cam = binding.make_camera(desc["eye"], desc["lookat"], desc["up"], desc["fov"])
+        # Below 64 samples per pixel the rays can be generated in the tiled order of mr_gen_eye_rays_tiled (a wave covers a
+        # square of pixels instead of a strip); tracing, shadow rays and shading are order-agnostic and work on pixel
+        # SLOTS, and the shaded slots are scattered to image order (d_rgb) with the window's pixel map.
+        # tiled=None: image order (ray k belongs to pixel k // spp in row-major order, what callers indexing d_rays /
+        # d_hits expect); tiled=True is the fast choice for whole frames
+        self.tiled = bool(tiled) and spp < 64 and spp & (spp - 1) == 0
+        if self.tiled and self.n_pixels:
+            maps, off = [], 0
+            for y0, y1 in self.bands:
+                maps.append(binding.tile_pixel_map(W, y1 - y0, spp).astype(np.int64) + off)
+                off += (y1 - y0) * W
+            self.d_slot_pixel = torch.from_numpy(np.concatenate(maps)).to(self.device)
+            self.d_slots = torch.zeros((self.n_pixels, 3), **f32)
+        else:
+            self.tiled = False
+            self.d_slots = self.d_rgb
 
     def bytes_resident(self):
-        return sum(t.numel() * t.element_size() for t in (self.d_rays, self.d_hits, self.d_shadow_rays,
-                                                          self.d_shadow_hits, self.d_src, self.d_count, self.d_rgb))
+        own = [self.d_rays, self.d_hits, self.d_shadow_rays, self.d_shadow_hits, self.d_src, self.d_count, self.d_rgb]
+        if self.tiled:
+            own += [self.d_slots, self.d_slot_pixel]
+        return sum(t.numel() * t.element_size() for t in own)
 
     def generate(self, stream=None):
         """Camera::eyeRay for every owned row; the rays then stay resident in HBM."""
@@ -142,7 +161,7 @@ class FrameRenderer:
         for y0, y1 in self.bands:
             k = (y1 - y0) * self.W * self.spp
             self.scene.gen_eye_rays(self.cam, self.W, self.H, self.d_rays[off:off + k], y0=y0, y1=y1, spp=self.spp,
-                                    jitter=self.jitter, seed=self.seed, stream=stream)
+                                    jitter=self.jitter, seed=self.seed, stream=stream, tiled=self.tiled)
             off += k
 
     def trace_primary(self, stream=None):
@@ -156,9 +175,20 @@ class FrameRenderer:
         fl = self.flags | (binding.MR_TRACE_ANY if any_hit else 0)
         self.scene.trace_indirect(self.d_shadow_rays, self.d_count, self.n, self.d_shadow_hits, fl, stream=stream)
 
+    def _untile(self, stream=None):
+        """slot order -> image order (a no-op for frames generated in image order)"""
+        if not self.tiled:
+            return
+        if isinstance(stream, torch.cuda.Stream):
+            with torch.cuda.stream(stream):
+                self.d_rgb.index_copy_(0, self.d_slot_pixel, self.d_slots)
+        else:
+            self.d_rgb.index_copy_(0, self.d_slot_pixel, self.d_slots)
+
     def shade(self, stream=None):
         self.scene.shade_direct(self.d_rays, self.d_hits, self.n, self.d_shadow_hits, self.d_src, self.d_count,
-                                self.desc["light"], self.desc["wattage"], self.d_rgb, spp=self.spp, stream=stream)
+                                self.desc["light"], self.desc["wattage"], self.d_slots, spp=self.spp, stream=stream)
+        self._untile(stream)
 
     def final_gather(self, global_map, caustic_map=None, nphotons=500, max_dist=1e10, stream=None):
         """BASELINE config 5: the photon-map term of Scene::traceScene (Scene.cpp:285-299) for the primary hits of this
@@ -167,8 +197,9 @@ class FrameRenderer:
             return
         if getattr(self, "d_gather", None) is None:
             self.d_gather = torch.empty(12 * self.n, dtype=torch.float32, device=self.device)
-        self.scene.final_gather(global_map, caustic_map, self.d_rays, self.d_hits, self.n, self.d_gather, self.d_rgb,
+        self.scene.final_gather(global_map, caustic_map, self.d_rays, self.d_hits, self.n, self.d_gather, self.d_slots,
                                 max_dist=max_dist, nphotons=nphotons, spp=self.spp, stream=stream)
+        self._untile(stream)
 
     def step(self, stream=None, any_hit=False):
         """One pass of the hot path over this rank's resident rays: primary batch, shadow batch, shade."""
@@ -202,7 +233,7 @@ class FrameRenderer:
         Fresnel / refract children of the next level by ballot compaction.  depth = TRACE_DEPTH (Miro.h:13): rays are
         traced while depth >= 0, i.e. up to depth+1 levels.  Returns the number of rays traced per level."""
         sc, L, W = self.scene, self.desc["light"], self.desc["wattage"]
-        self.d_rgb.zero_()
+        self.d_slots.zero_()
         rays, weights, pixels, n = self.d_rays, None, None, self.n
         per_level = []
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -217,7 +248,7 @@ class FrameRenderer:
             sc.trace_device(rays, n, hits, self.flags, stream=stream)
             sc.gen_shadow_rays(rays, hits, n, L, sh_rays, src, cnt, stream=stream)
             sc.trace_indirect(sh_rays, cnt, n, sh_hits, self.flags, stream=stream)       # closest hit: the occluder matters
-            sc.shade_accumulate(rays, hits, weights, pixels, n, sh_rays, sh_hits, src, cnt, L, W, self.d_rgb,
+            sc.shade_accumulate(rays, hits, weights, pixels, n, sh_rays, sh_hits, src, cnt, L, W, self.d_slots,
                                 spp=self.spp, stream=stream)
             n_shadow = int(cnt.item())
             per_level.append((n, n_shadow))
@@ -230,6 +261,7 @@ class FrameRenderer:
             sc.gen_secondary_rays(rays, hits, weights, pixels, n, out_rays, out_w, out_pix, cnt2, spp=self.spp, stream=stream)
             n = int(cnt2.item())
             rays, weights, pixels = out_rays[:n], out_w[:n], out_pix[:n]
+        self._untile(stream)
         return per_level
 
     def ray_counts(self):

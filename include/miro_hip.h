@@ -171,6 +171,18 @@ mr_status mr_trace_get_stats(mr_scene *scene, uint64_t *box_tests, uint64_t *tri
 mr_status mr_gen_eye_rays(mr_scene *scene, const mr_camera *cam, uint32_t W, uint32_t H,
                           uint32_t y0, uint32_t y1, uint32_t spp, uint32_t jitter, uint32_t seed,
                           mr_ray *d_rays, void *stream);
+/* The same rays in TILED order, for frames with fewer than 64 samples per pixel: the reference traces pixel by pixel
+ * (Scene.cpp:112-140) and has no batch order to keep, and a wave whose 64 rays cover a square of pixels shares far more
+ * of its BVH path than one on a 64 x 1 strip.  A pixel's spp rays stay consecutive (slot p = rays p*spp .. p*spp+spp-1);
+ * the window's rows are taken in groups of th, each group in blocks of tw pixels, each block row by row, with
+ * th x tw = 8x8, 8x4, 4x4, 4x2, 2x2, 2x1 for spp = 1, 2, 4, 8, 16, 32 (image order for any other spp).
+ * mr_tile_pixel_map writes, for the same window, pixel_of_slot[p] = (y - y0) * W + x into a HOST array of W * rows
+ * entries: everything downstream that works per ray (trace, shadow rays, shade) is order-agnostic, and a frame
+ * buffer shaded in slot order is scattered to image order with this map. */
+mr_status mr_gen_eye_rays_tiled(mr_scene *scene, const mr_camera *cam, uint32_t W, uint32_t H,
+                                uint32_t y0, uint32_t y1, uint32_t spp, uint32_t jitter, uint32_t seed,
+                                mr_ray *d_rays, void *stream);
+mr_status mr_tile_pixel_map(uint32_t W, uint32_t rows, uint32_t spp, uint32_t *pixel_of_slot);
 /* Phong::shade shadow ray (Phong.cpp:80-97) for every hit, compacted with a wave64 ballot /
  * prefix sum.  d_out needs room for n rays; d_src[k] = index of the originating ray (may be NULL);
  * d_count: device uint64 receiving the number of shadow rays (zeroed by the call).

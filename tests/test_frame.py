@@ -12,6 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from helpers import camera_of, oracle_scene, product_scene
+from miro_amd import binding
 from miro_amd import frame as mframe
 from miro_amd import scenes
 
@@ -239,3 +240,70 @@ def test_frame_step_captured_in_a_hip_graph(miro):
         g.replay()
     torch.cuda.synchronize()
     assert torch.equal(fr.d_rgb, ref) and fr.ray_counts() == counts
+
+
+# ---------------------------------------------------------------------------------------------- tiled ray order
+@pytest.mark.parametrize("W,rows,spp", [(16, 8, 1), (10, 5, 1), (7, 3, 4), (9, 9, 16), (5, 4, 64), (13, 11, 2), (4, 4, 3),
+                                        (1, 1, 1), (3, 17, 8), (64, 2, 32)])
+def test_tile_pixel_map_is_a_permutation_of_the_window(W, rows, spp):
+    """mr_tile_pixel_map: every pixel of the window exactly once, full blocks cover th x tw squares (one wave each)."""
+    m = binding.tile_pixel_map(W, rows, spp)
+    assert sorted(m.tolist()) == list(range(W * rows))
+    shapes = {1: (8, 8), 2: (8, 4), 4: (4, 4), 8: (4, 2), 16: (2, 2), 32: (2, 1)}
+    if spp in shapes and rows >= shapes[spp][0] and W >= shapes[spp][1]:
+        th, tw = shapes[spp]
+        first = m[:th * tw]
+        ys, xs = first // W, first % W
+        assert ys.max() == th - 1 and xs.max() == tw - 1 and len(set(first.tolist())) == th * tw
+    if spp not in shapes:
+        assert np.array_equal(m, np.arange(W * rows))          # image order
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,W,H,spp,y0,y1", [("teapot", 97, 64, 1, 0, 64), ("sponza", 50, 37, 4, 3, 30), ("bunny", 33, 20, 16, 0, 20),
+                                              ("teapot", 40, 24, 2, 8, 16), ("teapot", 31, 9, 64, 0, 9)])
+def test_tiled_eye_rays_are_the_same_rays_in_slot_order(miro, name, W, H, spp, y0, y1):
+    """mr_gen_eye_rays_tiled writes exactly the rays of mr_gen_eye_rays (bitwise, jitter included), slot p holding the
+    spp rays of pixel pixel_of_slot[p]."""
+    assert torch.cuda.is_available()
+    b = product_scene(miro, name)
+    cam = binding.make_camera(*(scenes.SCENES[name][k] for k in ("eye", "lookat", "up", "fov")))
+    n = (y1 - y0) * W * spp
+    lin = torch.empty((n, 8), dtype=torch.float32, device="cuda")
+    til = torch.empty((n, 8), dtype=torch.float32, device="cuda")
+    b.gen_eye_rays(cam, W, H, lin, y0=y0, y1=y1, spp=spp, jitter=spp > 1, seed=5)
+    b.gen_eye_rays(cam, W, H, til, y0=y0, y1=y1, spp=spp, jitter=spp > 1, seed=5, tiled=True)
+    m = torch.from_numpy(binding.tile_pixel_map(W, y1 - y0, spp).astype(np.int64)).cuda()
+    want = lin.view(-1, spp, 8)[m].reshape(-1, 8)
+    assert torch.equal(til.view(torch.int32), want.view(torch.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,spp", [("sponza", 1), ("bunny", 4), ("teapot", 16)])
+def test_tiled_frame_is_the_same_picture(miro, name, spp):
+    """The whole step on tiled rays, scattered back with the pixel map: byte-identical framebuffer, whole frame and
+    sharded in bands (ragged band heights included); the specular path and a HIP-graph replay likewise."""
+    b = product_scene(miro, name)
+    W, H = 150, 101
+    ref = mframe.FrameRenderer(b, name, W, H, spp=spp)
+    ref.generate(); ref.step()
+    want = ref.d_rgb.clone()
+    fr = mframe.FrameRenderer(b, name, W, H, spp=spp, tiled=True)
+    assert fr.tiled
+    fr.generate(); fr.step()
+    torch.cuda.synchronize()
+    assert torch.equal(fr.d_rgb, want)
+    assert ref.ray_counts() == fr.ray_counts()
+    for world, band in ((2, 8), (3, 5)):
+        full = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        for rank in range(world):
+            bands = mframe.band_rows(H, band, rank, world)
+            part = mframe.FrameRenderer(b, name, W, H, spp=spp, bands=bands, tiled=True)
+            part.generate(); part.step()
+            full[torch.from_numpy(mframe.rows_of(bands)).cuda()] = part.d_rgb.view(-1, W, 3)
+        assert torch.equal(full.view(-1, 3), want)
+    levels_ref = ref.render_specular(depth=2)
+    levels = fr.render_specular(depth=2)
+    torch.cuda.synchronize()
+    assert levels == levels_ref
+    assert torch.allclose(fr.d_rgb, ref.d_rgb, rtol=1e-5, atol=1e-7 * float(want.max()))

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--leaf", type=int, default=4)
     ap.add_argument("--incoherent", type=int, default=0, help="also time this many random rays")
     ap.add_argument("--no-host", action="store_true")
+    ap.add_argument("--tiled", action="store_true", help="camera rays in the tiled order of mr_gen_eye_rays_tiled")
     a = ap.parse_args()
     stream = torch.cuda.current_stream()
     for name in a.scenes:
@@ -41,7 +42,7 @@ def main():
         d_shh = torch.empty((n, 4), dtype=torch.float32, device="cuda")
         d_cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
         cam = binding.make_camera(d["eye"], d["lookat"], d["up"], d["fov"])
-        sc.gen_eye_rays(cam, a.w, a.h, d_rays, spp=a.spp, jitter=a.spp > 1, stream=stream)
+        sc.gen_eye_rays(cam, a.w, a.h, d_rays, spp=a.spp, jitter=a.spp > 1, stream=stream, tiled=a.tiled)
         sc.trace_device(d_rays, n, d_hits, stream=stream)
         sc.gen_shadow_rays(d_rays, d_hits, n, d["light"], d_sh, None, d_cnt, stream=stream)
         torch.cuda.synchronize()
