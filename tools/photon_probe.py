@@ -6,6 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "cse168-raytracer_amd"))
 import numpy as np, torch
 import miro_amd
+if os.environ.get("MIRO_LIB"):      # A/B: load another build of the library (see tools/ab_lib.py)
+    miro_amd.binding.load_library(os.path.abspath(os.environ["MIRO_LIB"]))
 from miro_amd import frame as mframe, scenes
 
 ap = argparse.ArgumentParser()
