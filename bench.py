@@ -120,6 +120,8 @@ def main():
                     help="MR_MATH_PRODUCT: slab distances as products with the rounded 1/d (about 25 %% faster; decisions can "
                          "differ from the reference's on 2-ulp ties)")
     ap.add_argument("--any-shadow", action="store_true", help="any-hit shadow batch (opaque scenes only)")
+    ap.add_argument("--tiled", action="store_true",
+                    help="camera rays in the tiled order of mr_gen_eye_rays_tiled (frames below 64 spp; no effect at 64)")
     ap.add_argument("--cpu-spp", type=int, default=8, help="samples per pixel of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -171,7 +173,7 @@ def main():
     # is waited for only when frame k+1 is about to overwrite that buffer, so it overlaps k+1's trace launches
     gather = mframe.FrameGather(H, W, a.band, rank, world, dev) if world > 1 else None
     fr = mframe.FrameRenderer(scene, desc, W, H, spp=spp, bands=bands, jitter=spp > 1, seed=168, flags=flags,
-                              rgb=gather.local if gather is not None and len(bands) else None)
+                              rgb=gather.local if gather is not None and len(bands) else None, tiled=a.tiled)
     fr.generate(stream)
     torch.cuda.synchronize()
 
@@ -259,6 +261,7 @@ def main():
                     "exact triangle test, slab distances as products with the rounded 1/d (MR_MATH_PRODUCT)" if a.product else
                     "exact: every quotient of the reference's slab and triangle tests, bit for bit"),
                 "shadow_query": "any-hit" if a.any_shadow else "closest-hit (as Phong.cpp:97)",
+                "ray_order": "tiled (mr_gen_eye_rays_tiled)" if fr.tiled else "image order",
                 "parallelism": "image rows in interleaved bands of %d over %d GPU(s), scene replicated, 1 RCCL gather of the framebuffer" % (a.band, world),
                 "resident_bytes_per_gpu": int(fr.bytes_resident() + info.device_bytes),
                 "bvh_build_s": round(t_build, 3),
