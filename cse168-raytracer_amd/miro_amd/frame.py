@@ -38,21 +38,25 @@ class FrameGather:
     `wait()` makes the caller's stream wait for it and, on `dst`, de-interleaves.  A renderer calls `wait()` just
     before it shades the next frame, so frame k's gather overlaps frame k+1's trace launches."""
 
-    def __init__(self, H, W, band, rank, world, device, dtype=torch.float32, group=None, dst=0, always_collective=False):
-        """always_collective: go through torch.distributed even when world == 1 (exercises the RCCL call on one GPU)"""
+    def __init__(self, H, W, band, rank, world, device, dtype=torch.float32, group=None, dst=0, always_collective=False,
+                 channels=3):
+        """always_collective: go through torch.distributed even when world == 1 (exercises the RCCL call on one GPU).
+        channels: values per pixel -- 3 for the float framebuffer; 4 * spp gathers the frame's mr_hit records instead
+        (the hit-buffer parity mode of SURVEY.md section 8e: 16 bytes per ray, viewed as float32)."""
+        self.channels = C = channels
         self.H, self.W, self.band, self.rank, self.world, self.group, self.dst = H, W, band, rank, world, group, dst
         self.local_only = world == 1 and not always_collective
         self.counts = [sum(y1 - y0 for y0, y1 in band_rows(H, band, r, world)) for r in range(world)]
         self.max_rows = max(self.counts)
-        self.send = torch.zeros((max(self.max_rows, 1) * W, 3), dtype=dtype, device=device)
-        self.local = self.send[:self.counts[rank] * W]            # [n_local_rows * W, 3], rows in band order
+        self.send = torch.zeros((max(self.max_rows, 1) * W, C), dtype=dtype, device=device)
+        self.local = self.send[:self.counts[rank] * W]            # [n_local_rows * W, C], rows in band order
         self.work = None
         self.pending = False
         self.full = None
         if rank == dst:
             self.recv = self.send.unsqueeze(0) if self.local_only else \
-                torch.empty((world, max(self.max_rows, 1) * W, 3), dtype=dtype, device=device)
-            self.full = torch.empty((H, W, 3), dtype=dtype, device=device)
+                torch.empty((world, max(self.max_rows, 1) * W, C), dtype=dtype, device=device)
+            self.full = torch.empty((H, W, C), dtype=dtype, device=device)
             dest = np.concatenate([rows_of(band_rows(H, band, r, world)) for r in range(world)])
             src = np.concatenate([r * max(self.max_rows, 1) + np.arange(self.counts[r], dtype=np.int64) for r in range(world)])
             self.dest_rows = torch.from_numpy(dest).to(device)
@@ -82,7 +86,7 @@ class FrameGather:
         self.work = dist.gather(self.send, recv, dst=self.dst, group=self.group, async_op=True)
 
     def wait(self):
-        """Returns the full [H, W, 3] frame on `dst` (valid for work enqueued after this call), None elsewhere."""
+        """Returns the full [H, W, channels] frame on `dst` (valid for work enqueued after this call), None elsewhere."""
         if not self.pending:
             return self.full
         if self.work is not None:
@@ -91,16 +95,18 @@ class FrameGather:
         self.pending = False
         if self.rank != self.dst:
             return None
-        rows = self.recv.reshape(-1, self.W * 3).index_select(0, self.src_rows)
-        self.full.view(self.H, self.W * 3).index_copy_(0, self.dest_rows, rows)
+        rows = self.recv.reshape(-1, self.W * self.channels).index_select(0, self.src_rows)
+        self.full.view(self.H, self.W * self.channels).index_copy_(0, self.dest_rows, rows)
         return self.full
 
 
 def gather_framebuffer(local_rgb, H, W, band, rank, world, group=None, dst=0):
-    """One-shot form of FrameGather: every rank contributes the rows it rendered ([n_local_rows*W, 3] floats, rows in
-    band order); rank `dst` receives them in one gather and de-interleaves into [H, W, 3]."""
-    g = FrameGather(H, W, band, rank, world, local_rgb.device, local_rgb.dtype, group, dst)
-    g.local.copy_(local_rgb.reshape(-1, 3)[:g.counts[rank] * W])
+    """One-shot form of FrameGather: every rank contributes the rows it rendered ([n_local_rows*W, C] values, rows in
+    band order; C = 3 for the framebuffer, 4*spp for hit records viewed as float32); rank `dst` receives them in one
+    gather and de-interleaves into [H, W, C]."""
+    C = local_rgb.shape[-1]
+    g = FrameGather(H, W, band, rank, world, local_rgb.device, local_rgb.dtype, group, dst, channels=C)
+    g.local.copy_(local_rgb.reshape(-1, C)[:g.counts[rank] * W])
     g.start()
     return g.wait()
 

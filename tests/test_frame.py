@@ -307,3 +307,55 @@ def test_tiled_frame_is_the_same_picture(miro, name, spp):
     torch.cuda.synchronize()
     assert levels == levels_ref
     assert torch.allclose(fr.d_rgb, ref.d_rgb, rtol=1e-5, atol=1e-7 * float(want.max()))
+
+
+def _hit_gather_worker(rank, world, port, H, W, band, spp, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows = mframe.rows_of(mframe.band_rows(H, band, rank, world))
+    # each rank's "hit buffer": spp records of 4 values per pixel, value encodes (row, column, sample, field)
+    C = 4 * spp
+    local = torch.empty((len(rows), W, C), dtype=torch.float32)
+    for i, y in enumerate(rows):
+        local[i] = (y * W + torch.arange(W, dtype=torch.float32))[:, None] * C + torch.arange(C, dtype=torch.float32)[None, :]
+    full = mframe.gather_framebuffer(local.reshape(-1, C), H, W, band, rank, world)
+    if rank == 0:
+        torch.save(full, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_hit_records_gloo_world2(tmp_path):
+    """The hit-buffer parity mode of SURVEY.md section 8e: the same single gather carries the ranks' mr_hit records
+    (4 * spp float32 values per pixel) instead of the framebuffer; rank 0 gets them in image order."""
+    H, W, band, spp = 21, 4, 5, 2
+    out = str(tmp_path / "hits.pt")
+    mp.spawn(_hit_gather_worker, args=(2, _free_port(), H, W, band, spp, out), nprocs=2, join=True)
+    full = torch.load(out, weights_only=True)
+    C = 4 * spp
+    want = torch.arange(H * W, dtype=torch.float32).reshape(H, W, 1) * C + torch.arange(C, dtype=torch.float32)
+    assert full.shape == (H, W, C) and torch.equal(full, want)
+
+
+@pytest.mark.gpu
+def test_sharded_hit_buffers_gather_to_the_unsharded_one(miro):
+    """Two shards' hit records through FrameGather's de-interleave (one process standing in for both ranks' send
+    buffers) equal the unsharded frame's hit buffer, record for record."""
+    W, H, spp, band, world = 96, 50, 2, 8, 2
+    b = product_scene(miro, "teapot")
+    whole = mframe.FrameRenderer(b, "teapot", W, H, spp=spp)
+    whole.generate(); whole.trace_primary()
+    g = mframe.FrameGather(H, W, band, 0, world, torch.device("cuda"), channels=4 * spp, always_collective=False)
+    parts = []
+    for rank in range(world):
+        bands = mframe.band_rows(H, band, rank, world)
+        fr = mframe.FrameRenderer(b, "teapot", W, H, spp=spp, bands=bands)
+        fr.generate(); fr.trace_primary()
+        parts.append(fr.d_hits.view(-1, 4 * spp))
+    for rank in range(world):                                # what dist.gather would have delivered to rank 0
+        g.recv[rank, :parts[rank].shape[0]] = parts[rank]
+    g.pending = True
+    full = g.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(full.view(-1, 4).view(torch.int32), whole.d_hits.view(torch.int32))
