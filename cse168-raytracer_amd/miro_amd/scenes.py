@@ -85,6 +85,83 @@ SCENES["a1sphere"] = dict(models=[], floor=None,
                           wattage=500.0)
 
 
+# ---------------------------------------------------------------------------------------------
+# makeBunny20Scene (assignment2.cpp:124-339): twenty transformed copies of bunny.obj.  The transforms are scene
+# constants, composed here with the reference's own fp32 arithmetic -- Matrix4x4::operator*= (Matrix4x4.h:463-493:
+# A = A * B, every element ((a*b + c*d) + e*f) + g*h in float) and translate / scale / rotate (assignment2.cpp:464-511:
+# angle in degrees, rad = angle * (PI / 180.) evaluated in double and stored as float, the axis NOT normalised).
+# The write-up publishes this scene's counters (writeup/A2/Readme.tex:97,101): 876 137 nodes, 438 069 leaves,
+# 495 502 rays with shadows = 262 144 primary + 233 358 hits; tests/test_oracle_kat.py reproduces them exactly.
+# ---------------------------------------------------------------------------------------------
+_F = np.float32
+
+
+def _mat_mul(A, B):
+    R = np.empty((4, 4), np.float32)
+    for i in range(4):
+        for j in range(4):
+            R[i, j] = _F(_F(_F(_F(A[i, 0] * B[0, j]) + _F(A[i, 1] * B[1, j])) + _F(A[i, 2] * B[2, j])) + _F(A[i, 3] * B[3, j]))
+    return R
+
+
+def _translate(x, y, z):
+    m = np.eye(4, dtype=np.float32)
+    m[0, 3], m[1, 3], m[2, 3] = _F(x), _F(y), _F(z)
+    return m
+
+
+def _scale(x, y, z):
+    m = np.eye(4, dtype=np.float32)
+    m[0, 0], m[1, 1], m[2, 2] = _F(x), _F(y), _F(z)
+    return m
+
+
+def _rotate(angle, x, y, z):
+    angle, x, y, z = _F(angle), _F(x), _F(y), _F(z)
+    pi = _F(3.1415926535897932384626433832795028841972)
+    rad = _F(float(angle) * (float(pi) / 180.0))
+    c, s = _F(np.cos(np.float64(rad))), _F(np.sin(np.float64(rad)))
+    x2, y2, z2 = _F(x * x), _F(y * y), _F(z * z)
+    cinv = _F(_F(1) - c)
+    xy, xz, yz, xs, ys, zs = _F(x * y), _F(x * z), _F(y * z), _F(x * s), _F(y * s), _F(z * s)
+    xzc, xyc, yzc = _F(xz * cinv), _F(xy * cinv), _F(yz * cinv)
+    m = np.eye(4, dtype=np.float32)
+    m[0, :3] = [_F(x2 + _F(c * _F(_F(1) - x2))), _F(_F(xy * cinv) + zs), _F(xzc - ys)]
+    m[1, :3] = [_F(xyc - zs), _F(y2 + _F(c * _F(_F(1) - y2))), _F(yzc + xs)]
+    m[2, :3] = [_F(xzc + ys), _F(yzc - xs), _F(z2 + _F(c * _F(_F(1) - z2)))]
+    return m
+
+
+def _bunny20_models():
+    T, S, R = _translate, _scale, _rotate
+    sequences = [[S(0.3, 2.0, 0.7), T(-1, .4, .3), R(25, .3, .1, .6)],
+                 [S(.6, 1.2, .9), T(7.6, .8, .6)],
+                 [T(.7, 0, -2), R(120, 0, .6, 1)],
+                 [T(3.6, 3, -1)],
+                 [T(-2.4, 2, 3), S(1, .8, 2)],
+                 [T(5.5, -.5, 1), S(1, 2, 1)],
+                 [R(15, 0, 0, 1), T(-4, -.5, -6), S(1, 2, 1)],
+                 [R(60, 0, 1, 0), T(5, .1, 3)],
+                 [T(-3, .4, 6), R(-30, 0, 1, 0)],
+                 [T(3, 0.5, -2), R(180, 0, 1, 0), S(1.5, 1.5, 1.5)]]
+    xform2 = np.eye(4, dtype=np.float32)
+    for m in (R(110, 0, 1, 0), S(.6, 1, 1.1)):                 # assignment2.cpp:150-152
+        xform2 = _mat_mul(xform2, m)
+    models = []
+    for start in (np.eye(4, dtype=np.float32), xform2):        # bunnies 1-10 from the identity, 11-20 from xform2
+        for seq in sequences:
+            m = start.copy()
+            for b in seq:
+                m = _mat_mul(m, b)
+            models.append(("bunny.obj", m))
+    return models
+
+
+SCENES["bunny20"] = dict(models=_bunny20_models(), floor=((-100, 0, -100), (0, 0, 100), (100, 0, -100)),
+                         eye=(0.0, 5.0, 15.0), lookat=(0.0, 0.0, 0.0), up=UP, fov=45.0, light=(10.0, 20.0, 10.0),
+                         wattage=1000.0)
+
+
 def sponza_label():
     p = os.environ.get("MIRO_SPONZA_OBJ", "")
     return "sponza" if p and os.path.exists(p) else "sponza-standin"

@@ -551,3 +551,23 @@ def test_large_host_batches_are_pipelined_in_chunks(oracle, miro, torch_cuda):
         assert b.stats() == ctr
     finally:
         pr.close(); ph.close()
+
+
+def test_bunny20_published_totals(oracle, miro, torch_cuda):
+    """makeBunny20Scene (1.39 M triangles, 876 137 nodes): the device finds the 233 358 primary hits behind the
+    write-up's 495 502 total rays (Readme.tex:97), every hit record equal to the oracle's, and the -DSTATS counters of
+    the primary and the shadow batch equal the oracle's."""
+    a, b = both(oracle, miro, "bunny20")
+    rays = oracle.eye_rays(camera_of(oracle, "bunny20"), 512, 512)
+    want, ctr = a.trace(rays, counters=True)
+    got = b.trace(rays.view(miro.RAY_DTYPE))
+    assert_hits_bit_exact(got, want.view(miro.HIT_DTYPE))
+    assert 262144 + int((got["prim"] != miro.MISS).sum()) == 495502
+    b.stats()
+    b.trace(rays.view(miro.RAY_DTYPE), flags=miro.MR_COUNT_STATS)
+    assert b.stats() == ctr
+    sh, _ = a.shadow_rays(rays, want, scenes.SCENES["bunny20"]["light"])
+    want_s, ctr_s = a.trace(sh, counters=True)
+    assert_hits_bit_exact(b.trace(sh.view(miro.RAY_DTYPE)), want_s.view(miro.HIT_DTYPE))
+    b.trace(sh.view(miro.RAY_DTYPE), flags=miro.MR_COUNT_STATS)
+    assert b.stats() == ctr_s

@@ -77,7 +77,7 @@ def test_missing_file_is_an_error(miro):
 
 
 @pytest.mark.parametrize("name,leaf", [("cornell", 4), ("teapot", 4), ("teapot", 8), ("bunny", 4), ("bunny", 8),
-                                       ("sponza", 4), ("sphere", 4), ("testobj", 4)])
+                                       ("sponza", 4), ("sphere", 4), ("testobj", 4), ("bunny20", 4)])
 def test_builder_tree_identical(oracle, miro, name, leaf):
     """BVH::build: same nodes (padded corners bit-equal), same topology, same leaf contents and order."""
     a = oracle_scene(oracle, name, leaf)
@@ -95,7 +95,8 @@ def test_builder_tree_identical(oracle, miro, name, leaf):
 def test_builder_known_answers(miro):
     """Stats::BVH_Nodes / BVH_LeafNodes of the reference (BASELINE.md section 2, Readme.tex:95-96)."""
     for name, leaf, want in (("teapot", 4, (385, 193)), ("teapot", 8, (199, 100)),
-                             ("bunny", 4, (42881, 21441)), ("bunny", 8, (23203, 11602))):
+                             ("bunny", 4, (42881, 21441)), ("bunny", 8, (23203, 11602)),
+                             ("bunny20", 4, (876137, 438069))):                       # Readme.tex:97
         i = product_scene(miro, name, leaf, host_only=True).info()
         assert (i.n_nodes, i.n_leaves) == want
 

@@ -81,6 +81,19 @@ def test_writeup_table_bunny(oracle, kat):
     assert 262144 + r["n_shadow"] == k["shadows"]["total_rays"]
 
 
+def test_writeup_table_bunny20(oracle, kat):
+    """Readme.tex:97,101 -- makeBunny20Scene: twenty bunnies under composed scale / translate / rotate matrices
+    (1 389 021 triangles).  876 137 nodes and 438 069 leaves pin the loader's ctm path (vertex = ctm * v with the
+    reference's Matrix4x4 arithmetic) and the builder at twenty times the size of the other scenes; 495 502 total rays
+    = 262 144 primary + 233 358 hits pins the traversal's hit / miss decisions there."""
+    k = kat["writeup"]["bunny20"]
+    s = oracle_scene(oracle, "bunny20", k["leaf_size"])
+    nodes, leaves, _ = s.tree_stats()
+    assert (nodes, leaves) == (k["nodes"], k["leaves"])
+    hits = s.trace(oracle.eye_rays(camera_of(oracle, "bunny20"), 512, 512))
+    assert 262144 + int((hits["prim"] != oracle.MISS).sum()) == k["shadows"]["total_rays"]
+
+
 def test_bunny_sse_counters(oracle, kat):
     k = kat["baseline"]["bunny_sse"]
     r = _render_counters(oracle, "bunny", 8, sse=True)
