@@ -664,6 +664,16 @@ mr_status mr_tonemap(mr_scene *s, const float *d_rgb, uint64_t n_values, uint8_t
     return launch_tonemap(d_rgb, n_values, d_out, static_cast<hipStream_t>(stream));
 }
 
+mr_status mr_untile_pixels(mr_scene *s, const float *d_slots, float *d_image, uint32_t W, uint32_t rows, uint32_t spp,
+                           uint32_t channels, void *stream) {
+    if (!s || !d_slots || !d_image) return fail(MR_ERR_INVALID, "NULL argument");
+    if (d_slots == d_image) return fail(MR_ERR_INVALID, "mr_untile_pixels does not work in place");
+    if (channels == 0 || spp == 0) return fail(MR_ERR_INVALID, "channels and spp must be positive");
+    if ((uint64_t)W * rows > 0xFFFFFFFFull) return fail(MR_ERR_INVALID, "window of more than 2^32-1 pixels");
+    MR_HIP_CHECK(hipSetDevice(s->device));
+    return launch_untile(d_slots, d_image, W, rows, spp, channels, static_cast<hipStream_t>(stream));
+}
+
 mr_status mr_hit_attrs(mr_scene *s, const mr_ray *d_rays, const mr_hit *d_hits, uint64_t n, float *d_P, float *d_N,
                        void *stream) {
     mr_status st = require_device(s);

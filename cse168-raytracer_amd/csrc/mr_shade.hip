@@ -11,6 +11,7 @@
 
 #include "mr_internal.h"
 #include "mr_surface.h"
+#include "mr_tile.h"
 
 namespace mr {
 namespace {
@@ -167,6 +168,19 @@ __global__ __launch_bounds__(kBlock) void tonemap_kernel(const float *rgb, unsig
     }
 }
 
+// pixel slots of a tiled window (mr_gen_eye_rays_tiled) -> image order: `channels` floats per pixel
+__global__ __launch_bounds__(kBlock) void untile_kernel(const float *slots, float *image, uint32_t W, uint32_t rows, TileShape t,
+                                                        uint32_t channels) {
+    const unsigned long long n = (unsigned long long)W * rows * channels;
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint32_t slot = (uint32_t)(i / channels), c = (uint32_t)(i - (unsigned long long)slot * channels);
+        uint32_t x, y;
+        tile_decode(slot, W, rows, t, x, y);
+        image[((unsigned long long)y * W + x) * channels + c] = slots[i];
+    }
+}
+
 inline unsigned grid_for(unsigned long long n) {
     unsigned long long blocks = (n + kBlock - 1) / kBlock;
     if (blocks > 256ull * 32ull) blocks = 256ull * 32ull;
@@ -221,6 +235,15 @@ mr_status launch_gather_accumulate(const float *d_irr_a, const float *d_irr_b, u
 mr_status launch_tonemap(const float *d_rgb, unsigned long long n_values, uint8_t *d_out, hipStream_t stream) {
     if (n_values == 0) return MR_OK;
     hipLaunchKernelGGL(tonemap_kernel, dim3(grid_for(n_values)), dim3(kBlock), 0, stream, d_rgb, n_values, d_out);
+    MR_HIP_CHECK(hipGetLastError());
+    return MR_OK;
+}
+
+mr_status launch_untile(const float *d_slots, float *d_image, uint32_t W, uint32_t rows, uint32_t spp, uint32_t channels,
+                        hipStream_t stream) {
+    const unsigned long long n = (unsigned long long)W * rows * channels;
+    if (n == 0) return MR_OK;
+    hipLaunchKernelGGL(untile_kernel, dim3(grid_for(n)), dim3(kBlock), 0, stream, d_slots, d_image, W, rows, tile_shape(spp), channels);
     MR_HIP_CHECK(hipGetLastError());
     return MR_OK;
 }

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "mr_scene_create", "mr_scene_destroy", "mr_scene_add_mesh", "mr_scene_add_obj", "mr_scene_add_triangle",
     "mr_scene_add_sphere", "mr_scene_add_plane",
     "mr_bvh_build", "mr_scene_get_info", "mr_scene_get_mesh", "mr_scene_export_tree",
-    "mr_trace", "mr_host_alloc", "mr_host_free", "mr_trace_indirect", "mr_trace_get_stats", "mr_gen_eye_rays", "mr_gen_eye_rays_tiled", "mr_tile_pixel_map", "mr_gen_shadow_rays", "mr_hit_attrs",
+    "mr_trace", "mr_host_alloc", "mr_host_free", "mr_trace_indirect", "mr_trace_get_stats", "mr_gen_eye_rays", "mr_gen_eye_rays_tiled", "mr_tile_pixel_map", "mr_untile_pixels", "mr_gen_shadow_rays", "mr_hit_attrs",
     "mr_shade_direct", "mr_tonemap",
     "mr_scene_set_materials", "mr_shade_accumulate", "mr_gen_secondary_rays",
     "mr_photon_map_create", "mr_photon_map_destroy", "mr_photon_map_store", "mr_photon_map_scale",
@@ -129,6 +129,7 @@ def load_library(path=None):
                                   C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     L.mr_gen_eye_rays_tiled.argtypes = L.mr_gen_eye_rays.argtypes
     L.mr_tile_pixel_map.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, u32p]
+    L.mr_untile_pixels.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     L.mr_gen_shadow_rays.argtypes = [vp, vp, vp, C.c_uint64, f32p, vp, vp, vp, vp]
     L.mr_hit_attrs.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, vp]
     L.mr_scene_add_sphere.argtypes = [vp, f32p, C.c_float, u32p]
@@ -344,6 +345,11 @@ class Scene:
         fn = self.L.mr_gen_eye_rays_tiled if tiled else self.L.mr_gen_eye_rays
         _check(fn(self.h, C.byref(cam), W, H, y0, y1, spp, 1 if jitter else 0, seed, d_rays.data_ptr(), _stream_ptr(stream)))
         return (y1 - y0) * W * spp
+
+    def untile_pixels(self, d_slots, d_image, W, rows, spp, channels=3, stream=None):
+        """Scatter a tiled window's pixel slots to image order on the device (mr_untile_pixels)."""
+        _check(self.L.mr_untile_pixels(self.h, d_slots.data_ptr(), d_image.data_ptr(), W, rows, spp, channels,
+                                       _stream_ptr(stream)))
 
     def gen_shadow_rays(self, d_rays, d_hits, n, light, d_out, d_src, d_count, stream=None):
         l = np.ascontiguousarray(light, dtype=np.float32)

@@ -183,6 +183,10 @@ mr_status mr_gen_eye_rays_tiled(mr_scene *scene, const mr_camera *cam, uint32_t 
                                 uint32_t y0, uint32_t y1, uint32_t spp, uint32_t jitter, uint32_t seed,
                                 mr_ray *d_rays, void *stream);
 mr_status mr_tile_pixel_map(uint32_t W, uint32_t rows, uint32_t spp, uint32_t *pixel_of_slot);
+/* The scatter itself, on the device: d_image[((y - y0) * W + x) * channels + c] = d_slots[p * channels + c] for every
+ * pixel slot p of the window (channels = 3 for the float framebuffer of mr_shade_direct).  Not in place. */
+mr_status mr_untile_pixels(mr_scene *scene, const float *d_slots, float *d_image, uint32_t W, uint32_t rows,
+                           uint32_t spp, uint32_t channels, void *stream);
 /* Phong::shade shadow ray (Phong.cpp:80-97) for every hit, compacted with a wave64 ballot /
  * prefix sum.  d_out needs room for n rays; d_src[k] = index of the originating ray (may be NULL);
  * d_count: device uint64 receiving the number of shadow rays (zeroed by the call).

@@ -359,3 +359,20 @@ def test_sharded_hit_buffers_gather_to_the_unsharded_one(miro):
     full = g.wait()
     torch.cuda.synchronize()
     assert torch.equal(full.view(-1, 4).view(torch.int32), whole.d_hits.view(torch.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,rows,spp,channels", [(150, 101, 1, 3), (33, 7, 4, 3), (64, 64, 16, 1), (5, 3, 2, 8), (40, 9, 64, 3)])
+def test_untile_pixels_on_the_device_follows_the_pixel_map(miro, W, rows, spp, channels):
+    """mr_untile_pixels == scattering with mr_tile_pixel_map, for ragged windows and any channel count."""
+    b = product_scene(miro, "testobj")
+    slots = torch.arange(W * rows * channels, dtype=torch.float32, device="cuda").view(-1, channels)
+    image = torch.full_like(slots, -1.0)
+    b.untile_pixels(slots, image, W, rows, spp, channels=channels)
+    m = torch.from_numpy(binding.tile_pixel_map(W, rows, spp).astype(np.int64)).cuda()
+    want = torch.empty_like(slots)
+    want[m] = slots
+    torch.cuda.synchronize()
+    assert torch.equal(image, want)
+    with pytest.raises(miro.MiroError):
+        b.untile_pixels(slots, slots, W, rows, spp, channels=channels)
