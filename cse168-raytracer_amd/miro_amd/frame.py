@@ -185,6 +185,10 @@ class FrameRenderer:
         """slot order -> image order (a no-op for frames generated in image order)"""
         if not self.tiled:
             return
+        if len(self.bands) == 1:            # one window: the library's own scatter, on the caller's stream
+            y0, y1 = self.bands[0]
+            self.scene.untile_pixels(self.d_slots, self.d_rgb, self.W, y1 - y0, self.spp, channels=3, stream=stream)
+            return
         if isinstance(stream, torch.cuda.Stream):
             with torch.cuda.stream(stream):
                 self.d_rgb.index_copy_(0, self.d_slot_pixel, self.d_slots)
