@@ -224,11 +224,13 @@ def test_frame_gather_through_rccl_single_rank():
 
 
 @gpu
-def test_frame_step_captured_in_a_hip_graph(miro):
-    """The whole step (trace -> shadow rays -> indirect trace -> shade) records into a HIP graph on the stream it is
-    given -- no hidden synchronisation or allocation inside the C ABI calls -- and replays to the same picture."""
+@pytest.mark.parametrize("tiled", [False, True])
+def test_frame_step_captured_in_a_hip_graph(miro, tiled):
+    """The whole step (trace -> shadow rays -> indirect trace -> shade [-> untile]) records into a HIP graph on the
+    stream it is given -- no hidden synchronisation or allocation inside the C ABI calls -- and replays to the same
+    picture."""
     b = product_scene(miro, "teapot")
-    fr = mframe.FrameRenderer(b, "teapot", 160, 120, spp=2)
+    fr = mframe.FrameRenderer(b, "teapot", 160, 120, spp=2, tiled=tiled)
     fr.generate()
     fr.step()
     torch.cuda.synchronize()
