@@ -181,6 +181,11 @@ mr_status flatten_and_upload(mr_scene *s) {
 // default: one white Lambert = Phong(Vector3(1)) (Lambert.h:9, Phong.h:10-14: shininess 1, index 1)
 mr_status upload_materials(mr_scene *s) {
     DeviceScene &d = s->dev;
+    // the kernels index prim_material[] with every object of the scene: a table set before later geometry was added
+    // would be read out of bounds (mr_surface.h material_id)
+    if (!s->prim_material.empty() && s->prim_material.size() != s->mesh.n_triangles())
+        return fail(MR_ERR_STATE, "mr_scene_set_materials covered %zu objects, the scene now holds %u: set the materials "
+                                  "again after the last object was added", s->prim_material.size(), s->mesh.n_triangles());
     (void)hipFree(d.materials); (void)hipFree(d.prim_material);
     d.materials = nullptr; d.prim_material = nullptr;
     static const float white[11] = {1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1};
@@ -425,8 +430,10 @@ mr_status mr_trace(mr_scene *s, const mr_ray *rays, uint64_t n, mr_hit *hits, ui
     if (!rays_dev || !hits_dev) {
         staged.lock();
         if ((st = ensure_stage(s, n)) != MR_OK) return st;
+        // batches above kStageChunk are uploaded chunk by chunk on the copy stream below; smaller ones in one piece here
         if (!rays_dev) {
-            MR_HIP_CHECK(hipMemcpyAsync(s->d_stage_rays, rays, n * sizeof(mr_ray), hipMemcpyHostToDevice, stream));
+            if (n <= kStageChunk)
+                MR_HIP_CHECK(hipMemcpyAsync(s->d_stage_rays, rays, n * sizeof(mr_ray), hipMemcpyHostToDevice, stream));
             d_rays = static_cast<const mr_ray *>(s->d_stage_rays);
         }
         if (!hits_dev) d_hits = static_cast<mr_hit *>(s->d_stage_hits);
@@ -447,7 +454,9 @@ mr_status mr_trace(mr_scene *s, const mr_ray *rays, uint64_t n, mr_hit *hits, ui
         if ((st = ensure_copy_pipeline(s, n_chunks)) != MR_OK) return st;
         // (alternating the uploads between two copy streams changes nothing: one queue already fills the link, 27 GB/s up)
         hipStream_t in = static_cast<hipStream_t>(s->copy_in), out = static_cast<hipStream_t>(s->copy_out);
-        for (uint64_t k = 0; k < n_chunks; k++) {
+        // one chunk; on any failure the three streams are drained before stage_mutex is released, so that the next
+        // caller never shares the staging buffers with copies still in flight
+        auto chunk = [&](uint64_t k) -> mr_status {
             const uint64_t off = k * kStageChunk, m = n - off < kStageChunk ? n - off : kStageChunk;
             hipEvent_t up = static_cast<hipEvent_t>(s->stage_events[2 * k]), done = static_cast<hipEvent_t>(s->stage_events[2 * k + 1]);
             if (!rays_dev) {
@@ -456,15 +465,19 @@ mr_status mr_trace(mr_scene *s, const mr_ray *rays, uint64_t n, mr_hit *hits, ui
                 MR_HIP_CHECK(hipStreamWaitEvent(stream, up, 0));
             }
             p.rays = d_rays + off; p.hits = d_hits + off; p.n = m;
-            if ((st = launch_trace(p, flags, stream)) != MR_OK) return st;
+            const mr_status lst = launch_trace(p, flags, stream);
+            if (lst != MR_OK) return lst;
             if (!hits_dev) {
                 MR_HIP_CHECK(hipEventRecord(done, stream));
                 MR_HIP_CHECK(hipStreamWaitEvent(out, done, 0));
                 MR_HIP_CHECK(hipMemcpyAsync(hits + off, d_hits + off, m * sizeof(mr_hit), hipMemcpyDeviceToHost, out));
             }
-        }
-        if (!hits_dev) MR_HIP_CHECK(hipStreamSynchronize(out));
-        MR_HIP_CHECK(hipStreamSynchronize(stream));
+            return MR_OK;
+        };
+        for (uint64_t k = 0; k < n_chunks && st == MR_OK; k++) st = chunk(k);
+        const hipError_t e_in = hipStreamSynchronize(in), e_run = hipStreamSynchronize(stream), e_out = hipStreamSynchronize(out);
+        if (st != MR_OK) return st;           // the failing call's message is the one mr_last_error() keeps
+        MR_HIP_CHECK(e_in); MR_HIP_CHECK(e_run); MR_HIP_CHECK(e_out);
         return MR_OK;
     }
     if ((st = launch_trace(p, flags, stream)) != MR_OK) return st;

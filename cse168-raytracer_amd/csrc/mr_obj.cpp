@@ -179,6 +179,12 @@ mr_status load_obj(const char *path, const float *ctm16, HostMesh &mesh, uint32_
     }
     for (uint32_t ni : nidx)
         if (ni >= normals.size()) return fail(MR_ERR_IO, "\"%s\": normal index %u out of range", path, ni + 1);
+    // An explicit normal index on corner 0 or 1 of a face whose last corner has none never reaches nidx (the face's
+    // slots are overwritten by the synthesised ones) but still takes part in the smoothing pass below, as in the
+    // reference (TriangleMeshLoad.cpp:226-248 record it before :252 decides): it has to be in range as well.
+    for (auto &e : incidence)
+        if (e.second >= normals.size())
+            return fail(MR_ERR_IO, "\"%s\": normal index %u out of range", path, e.second + 1);
 
     // smooth the synthesised normals: CSR of (vertex -> incident normal slots) in encounter order
     {

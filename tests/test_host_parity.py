@@ -1,6 +1,8 @@
 """Host logic of the product (OBJ ingestion, BVH::build) against the oracle -- no GPU needed.
 The product is built host_only here; nothing is computed by a device and nothing falls back to the CPU
 for tracing (mr_trace on a host_only scene is an error, see test_abi.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -69,6 +71,29 @@ def test_loader_edge_cases(oracle, miro, tmp_path):
         assert np.array_equal(_bits(x), _bits(y))
 
 
+def test_stale_normal_index_on_a_face_without_last_normal_is_refused(oracle, miro, tmp_path):
+    """corner 0/1 carry an out-of-range (or negative) normal index, the last corner has none.  The face gets
+    synthesised normals, so the bad index never reaches the face table -- but it is in the vertex's incidence list of
+    the smoothing pass (TriangleMeshLoad.cpp:226-248 run before :252), which used to read normals[] out of bounds."""
+    for k, face in enumerate(["f 1//400000000 2//400000000 3", "f 1//-7 2 3", "f 1 2//9 3"]):
+        p = tmp_path / ("stale%d.obj" % k)
+        p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\n" + face + "\n")
+        with pytest.raises(Exception):
+            oracle.Scene().add_obj(str(p))
+        with pytest.raises(miro.MiroError) as e:
+            miro.Scene().add_obj(str(p))
+        assert e.value.status == -2
+    # in-range forms of the same shape are accepted and equal the oracle's arrays -- including an index that lands on
+    # one of the face's own synthesised slots ("f 1/1/3 ..." with one vn: slot 2 exists once the face is synthesised)
+    for k, body in enumerate(["vn 1 0 0\nf 1//2 2//1 3\nf 3 2//2 1//1\n", "f 1/1/3 2/1/1 3\n"]):
+        p = tmp_path / ("stale_ok%d.obj" % k)
+        p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\n" + body)
+        a, b = oracle.Scene(), miro.Scene()
+        assert a.add_obj(str(p)) == b.add_obj(str(p))
+        for x, y in zip(a.arrays(), b.arrays()):
+            assert np.array_equal(_bits(x), _bits(y))
+
+
 def test_missing_file_is_an_error(miro):
     s = miro.Scene()
     with pytest.raises(miro.MiroError) as e:
@@ -99,6 +124,12 @@ def test_builder_known_answers(miro):
                              ("bunny20", 4, (876137, 438069))):                       # Readme.tex:97
         i = product_scene(miro, name, leaf, host_only=True).info()
         assert (i.n_nodes, i.n_leaves) == want
+    # Readme.tex:103-106: makeCornellScene's four meshes, 21 nodes / 11 leaves
+    s = miro.Scene()
+    for k in range(1, 5):
+        s.add_obj(os.path.join(os.path.dirname(__file__), "golden", "models", "cornell_box_%d.obj" % k))
+    i = s.build(4, host_only=True)
+    assert (i.n_nodes, i.n_leaves) == (21, 11)
 
 
 def test_builder_degenerate_inputs(oracle, miro):
@@ -180,7 +211,8 @@ def _mutate(text, rng):
     record."""
     lines = text.split("\n")
     hostile = ["f -1 -2 -3", "f 0 0 0", "f 1 2 99999", "f 1/1/77 2/1/1 3/1/1", "f 1 2", "f", "v", "v 1e39 nan inf",
-               "vn 0 0 0", "f 1//1 2//1 3", "v 1 2", "f 4294967297 2 3", "f a b c", "vn", "f 1/ 2/ 3/", "\x00", "v " + "9" * 120]
+               "vn 0 0 0", "f 1//1 2//1 3", "v 1 2",
+               "f 1//400000000 2//400000000 3", "f 1//-5 2//1 3", "f 1/1/99 2 3", "f 2//0 3//77 1", "f 4294967297 2 3", "f a b c", "vn", "f 1/ 2/ 3/", "\x00", "v " + "9" * 120]
     for _ in range(int(rng.integers(1, 4))):
         k = int(rng.integers(0, 6))
         i = int(rng.integers(0, len(lines)))

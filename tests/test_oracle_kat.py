@@ -94,6 +94,18 @@ def test_writeup_table_bunny20(oracle, kat):
     assert 262144 + int((hits["prim"] != oracle.MISS).sum()) == k["shadows"]["total_rays"]
 
 
+def test_writeup_table_cornell(oracle, kat, golden_dir):
+    """Readme.tex:103-106 -- both Cornell rows report 21 nodes / 11 leaves: makeCornellScene's four meshes
+    (assignment2.cpp:413-429) under the scalar build's 4 triangles per leaf."""
+    k = kat["writeup"]["cornell"]
+    s = oracle.Scene()
+    for i in range(1, 5):
+        s.add_obj(os.path.join(golden_dir, "models", "cornell_box_%d.obj" % i))
+    s.build(k["leaf_size"])
+    nodes, leaves, _ = s.tree_stats()
+    assert (nodes, leaves) == (k["nodes"], k["leaves"])
+
+
 def test_bunny_sse_counters(oracle, kat):
     k = kat["baseline"]["bunny_sse"]
     r = _render_counters(oracle, "bunny", 8, sse=True)
