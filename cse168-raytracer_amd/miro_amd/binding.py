@@ -22,6 +22,7 @@ MR_MATH_FAST = 1 << 3
 MR_COUNT_STATS = 1 << 4
 MR_TRACE_PERSISTENT = 1 << 5
 MR_MATH_PRODUCT = 1 << 6
+MR_TRACE_INCOHERENT = 1 << 7
 
 MR_OK, MR_ERR_INVALID, MR_ERR_IO, MR_ERR_NOMEM, MR_ERR_HIP, MR_ERR_STATE = 0, -1, -2, -3, -4, -5
 

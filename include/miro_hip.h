@@ -99,6 +99,11 @@ enum {
                                       it on random rays, slower on coherent camera rays -- off by default;
                                       triangle scenes only: ignored, i.e. the default kernel runs, when the scene holds
                                       spheres or planes, and under MR_COUNT_STATS / MR_MATH_FAST) */
+    MR_TRACE_INCOHERENT = 1u << 7, /* batch hint: the 64 rays of a wave do not share their path through the tree (secondary,
+                                      random or 1-sample-per-pixel batches).  Selects the voting control flow: every
+                                      iteration a wave runs the step (node test / triangle test) most of its lanes need,
+                                      instead of running node tests until its slowest lane has found a leaf.  Same per-ray
+                                      steps in the same order: identical hit records.  Combines with MR_TRACE_PERSISTENT */
     MR_MATH_PRODUCT   = 1u << 6    /* slab distances as products (corner - o) * RN(1/d) instead of the reference's
                                       quotients (corner - o) / d (BVH.cpp:601-602), which the default reproduces bit for
                                       bit (one fma correction step per product: exactly the correctly rounded quotient
