@@ -1,26 +1,38 @@
 #!/usr/bin/env python3
 """bench.py -- Mrays/s (primary + shadow) of the HIP intersection path on BASELINE config 4
-(sponza 1920x1080, 64 spp), with the kernel's roofline and the CPU (SSE) baseline beside it.
+(sponza 1920x1080, 64 spp), with the dominant kernel's roofline and the CPU (SSE) baseline beside it.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path over one frame's rays, which are generated once and stay resident in HBM:
-primary batch (mr_trace) -> shadow batch built on the device (ballot compaction) -> mr_trace_indirect ->
-Phong shade into the float framebuffer; with N > 1 the frame's rows are dealt to the ranks in interleaved
-bands and the step ends with the single RCCL gather of the framebuffer.  Total work is fixed => "strong".
-Rank 0 prints ONE JSON line.
+A step = one pass of the hot path over one frame, everything inside the timed region: mr_render_direct generates every
+primary ray from the camera (Camera::eyeRay), traces it, builds and traces the shadow ray of every hit and shades the
+sample, in ONE launch of frame_kernel (no ray buffers; `--batched` runs the round-1 pipeline of five kernels over
+resident ray buffers instead).  With N > 1 the frame's rows are dealt to the ranks in interleaved bands and every step
+ends with the single RCCL gather of the framebuffer.  Total work is fixed => "strong".  Rank 0 prints ONE JSON line.
+
+The `roofline` object states the resource that bounds the kernel -- VALU issue -- from SQ counters: achieved = wave-level
+VALU instructions per launch (SQ_INSTS_VALU, collected by a rocprofv3 --pmc pass over this same workload started from
+inside this run; the committed profiles/r02_bench_pmc.json when the profiler is unavailable) / the launch duration
+measured here with HIP events; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction.  The HBM figures of
+SURVEY.md section 8(d) ride along, labelled as what they are: the nominal algorithmic-bytes rate (cache-resident, not a
+bound) and the measured HBM traffic (PMC FETCH_SIZE x 2 + WRITE_SIZE) as a fraction of the 8 TB/s peak.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "cse168-raytracer_amd"))
 
-import numpy as np  # noqa: E402
+import numpy as np  # noqa: E402,F401
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -29,6 +41,11 @@ from miro_amd import frame as mframe  # noqa: E402
 from miro_amd import scenes  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+N_SIMD = 1024                # 256 CUs x 4 SIMD-32
+CLOCK_GHZ = 2.4              # MI355X_MICROARCH.md: peak engine clock
+VALU_PEAK_GINSTR = N_SIMD * CLOCK_GHZ / 2.0    # a wave64 VALU instruction holds its SIMD-32 for 2 cycles (guide, line 54/473)
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_bench_pmc.json")
+SQ_COUNTERS = "SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY"
 
 
 def algorithmic_bytes_per_ray(V, T):
@@ -56,51 +73,116 @@ def reference_counts(scene, fr_args, light):
     return (cp[0] / max(n_p, 1), cp[1] / max(n_p, 1)), (cs[0] / max(n_s, 1), cs[1] / max(n_s, 1)), (n_p, n_s)
 
 
-def cpu_baseline(desc, label, W, H, spp, threads):
+def cgroup_cpu_quota():
+    """CPU quota of this process's cgroup in cores (cgroup v2 cpu.max or v1 cfs quota), or None when unlimited."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
+def cpu_baseline(desc, label, W, H, spp):
     """The reference's SSE packet path (oracle/miro_oracle_sse.c, a port: the reference itself cannot travel or
-    be built here) on the host cores, on a bounded sample of the same workload; trace batches only."""
+    be built here) on the host cores this process may use, on a bounded sample of the same workload; trace batches
+    only.  Thread counts tried: every core of the affinity mask (capped by the cgroup's CPU quota when there is one)
+    and, when that is more than 32, also 16 -- a GPU box of the pool is shared by eight jobs and its documented
+    per-GPU CPU share is 16 cores; the best rate is `value`, every run is listed."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
+    affinity = len(os.sched_getaffinity(0))
+    quota = cgroup_cpu_quota()
+    allotted = affinity if quota is None else max(1, min(affinity, int(quota + 0.999)))
+    env_threads = int(os.environ.get("MIRO_CPU_THREADS", "0"))
+    tries = [env_threads] if env_threads else ([allotted] + ([16] if allotted > 32 else []))
     s = po.Scene()
     scenes.populate(s, desc)
     s.build(8)
     cam = po.make_camera(desc["eye"], desc["lookat"], desc["up"], desc["fov"])
     rays = po.eye_rays(cam, W, H, spp=spp, jitter=spp > 1, seed=168)
-    t0 = time.perf_counter()
-    hits, used = s.trace_sse(rays, threads=threads)
-    t1 = time.perf_counter()
-    sh, _ = s.shadow_rays(rays, hits, desc["light"], sse_order=True)
-    t2 = time.perf_counter()
-    s.trace_sse(sh, threads=threads)
-    t3 = time.perf_counter()
-    n = len(rays) + len(sh)
-    secs = (t1 - t0) + (t3 - t2)
+    runs, sh = [], None
+    for threads in tries:
+        t0 = time.perf_counter()
+        hits, used = s.trace_sse(rays, threads=threads)
+        t1 = time.perf_counter()
+        if sh is None:
+            sh, _ = s.shadow_rays(rays, hits, desc["light"], sse_order=True)
+        t2 = time.perf_counter()
+        s.trace_sse(sh, threads=threads)
+        t3 = time.perf_counter()
+        secs = (t1 - t0) + (t3 - t2)
+        runs.append(dict(threads=int(used), mrays_s=round((len(rays) + len(sh)) / secs / 1e6, 3), wall_s=round(secs, 3)))
+    best = max(runs, key=lambda r: r["mrays_s"])
     # the same path on one thread (SURVEY.md section 8d asks for both), on every spp-th ray of the sample
     r1, s1 = rays[::max(spp, 1)].copy(), sh[::max(spp, 1)].copy()
     t4 = time.perf_counter()
     s.trace_sse(r1, threads=1)
     s.trace_sse(s1, threads=1)
     t5 = time.perf_counter()
-    return dict(value=round(n / secs / 1e6, 3), unit="Mrays/s", cores=int(used), kind="port",
-                single_thread_mrays_s=round((len(r1) + len(s1)) / (t5 - t4) / 1e6, 3),
+    return dict(value=best["mrays_s"], unit="Mrays/s", cores=best["threads"], kind="port",
+                threads_used=best["threads"], affinity_cores=affinity, cgroup_quota_cores=quota, host_cpus=os.cpu_count(),
+                runs=runs, single_thread_mrays_s=round((len(r1) + len(s1)) / (t5 - t4) / 1e6, 3),
                 sample="%s %dx%d %d spp: %d primary + %d shadow rays, SSE4.1 packet path (8 tris/leaf), OpenMP "
-                       "dynamic chunks of 1024 rays, %.2f s wall" % (label, W, H, spp, len(rays), len(sh), secs))
+                       "dynamic chunks of 1024 rays; value = the best of the listed runs (%d threads, %.2f s wall)"
+                       % (label, W, H, spp, len(rays), len(sh), best["threads"], best["wall_s"]))
 
 
-def load_traffic(workload):
-    """HBM bytes per trace launch from the committed PMC profile (profiles/*traffic*.json), or None."""
-    pdir = os.path.join(ROOT, "profiles")
-    best = None
-    if os.path.isdir(pdir):
-        for f in sorted(os.listdir(pdir)):
-            if f.endswith(".json") and "traffic" in f:
-                try:
-                    j = json.load(open(os.path.join(pdir, f)))
-                except Exception:
-                    continue
-                if j.get("workload") == workload:
-                    best = j
-    return best
+# ------------------------------------------------------------------------------------------------ PMC (rocprofv3)
+def _counter_means(out_dir, kernel_substr):
+    """counter -> mean over the dispatches of the kernel whose name holds `kernel_substr`"""
+    acc = {}
+    for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if kernel_substr in row.get("Kernel_Name", ""):
+                    acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, (max((len(v) for v in acc.values()), default=0))
+
+
+def live_pmc(argv_leg, kernel_substr, timeout_s=200):
+    """Three rocprofv3 --pmc passes (SQ counters; FETCH_SIZE; WRITE_SIZE -- the TCC pair does not fit one pass) over
+    `python3 bench.py --pmc-leg ...`, i.e. over the same frame this run times.  Returns the counter means per launch of
+    the frame kernel, or None when the profiler is missing / fails / times out."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="miro_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for tag, counters in (("sq", SQ_COUNTERS), ("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            d = os.path.join(tmp, tag)
+            cmd = [exe, "--pmc"] + counters.split() + ["--output-format", "csv", "-d", d, "--", sys.executable,
+                                                       os.path.abspath(__file__)] + argv_leg
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=env)
+            if r.returncode != 0:
+                return None, "rocprofv3 pass '%s' failed: %s" % (tag, (r.stderr or r.stdout)[-300:])
+            means, n = _counter_means(d, kernel_substr)
+            if not means:
+                return None, "rocprofv3 pass '%s' recorded no %s dispatch" % (tag, kernel_substr)
+            out.update(means)
+            out["dispatches_" + tag] = n
+        return out, None
+    except subprocess.TimeoutExpired:
+        return None, "rocprofv3 timed out"
+    except Exception as e:      # a missing profiler must never take the bench line down
+        return None, "rocprofv3 could not run: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def committed_pmc(workload):
+    try:
+        j = json.load(open(PMC_FILE))
+    except Exception:
+        return None
+    return j if j.get("per_sample") else None      # per-sample figures: scaled to the launch at hand by the caller
 
 
 def main():
@@ -115,15 +197,19 @@ def main():
     ap.add_argument("--band", type=int, default=0,
                     help="rows per interleaved band when sharding the image (0: the largest height <= 8 that gives every "
                          "rank the same number of bands, else 8)")
-    ap.add_argument("--fast", action="store_true", help="MR_MATH_FAST (not the parity mode; never the default)")
     ap.add_argument("--product", action="store_true",
                     help="MR_MATH_PRODUCT: slab distances as products with the rounded 1/d (about 25 %% faster; decisions can "
                          "differ from the reference's on 2-ulp ties)")
-    ap.add_argument("--any-shadow", action="store_true", help="any-hit shadow batch (opaque scenes only)")
-    ap.add_argument("--tiled", action="store_true",
-                    help="camera rays in the tiled order of mr_gen_eye_rays_tiled (frames below 64 spp; no effect at 64)")
+    ap.add_argument("--incoherent", action="store_true", help="MR_TRACE_INCOHERENT: the voting control flow")
+    ap.add_argument("--any-shadow", action="store_true", help="any-hit shadow rays (opaque scenes only)")
+    ap.add_argument("--batched", action="store_true",
+                    help="the round-1 pipeline: resident ray buffers, five kernels per step (eye rays generated once, outside "
+                         "the step)")
+    ap.add_argument("--image-order", action="store_true", help="samples in image order instead of the tiled order (< 64 spp)")
     ap.add_argument("--cpu-spp", type=int, default=8, help="samples per pixel of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 passes (use profiles/r02_bench_pmc.json)")
+    ap.add_argument("--pmc-leg", action="store_true", help=argparse.SUPPRESS)   # internal: the profiled child
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -163,48 +249,79 @@ def main():
     if a.band <= 0:      # 1080 rows: 8 ranks -> 5 (27 bands each), 4 -> 6, 2 -> 6; bands of 8 would leave 17 vs 16
         a.band = next((b for b in range(8, 0, -1) if H % b == 0 and (H // b) % world == 0), 8)
     bands = mframe.band_rows(H, a.band, rank, world)
-    flags = miro_amd.MR_MATH_FAST if a.fast else (miro_amd.MR_MATH_PRODUCT if a.product else 0)
+    flags = (miro_amd.MR_MATH_PRODUCT if a.product else 0) | (miro_amd.MR_TRACE_INCOHERENT if a.incoherent else 0)
     stream = torch.cuda.current_stream()
+    fused = not a.batched and spp <= 64 and spp & (spp - 1) == 0
+    tiled = not a.image_order and spp < 64
 
-    (Vp, Tp), (Vs, Ts), _ = reference_counts(scene, (desc, W, H, bands, 168), desc["light"])
-    Bp, Bs = algorithmic_bytes_per_ray(Vp, Tp), algorithmic_bytes_per_ray(Vs, Ts)
-
-    # multi-GPU: the shard is shaded straight into the gather's send buffer; the gather of frame k is asynchronous and
-    # is waited for only when frame k+1 is about to overwrite that buffer, so it overlaps k+1's trace launches
-    gather = mframe.FrameGather(H, W, a.band, rank, world, dev) if world > 1 else None
-    fr = mframe.FrameRenderer(scene, desc, W, H, spp=spp, bands=bands, jitter=spp > 1, seed=168, flags=flags,
-                              rgb=gather.local if gather is not None and len(bands) else None, tiled=a.tiled)
-    fr.generate(stream)
+    # multi-GPU: two send buffers, used by alternate frames, so that frame k's gather (asynchronous, RCCL's own stream)
+    # overlaps frame k+1's launch -- the kernel of frame k+1 writes the other buffer
+    gathers = [mframe.FrameGather(H, W, a.band, rank, world, dev) for _ in range(2)] if world > 1 else None
+    if fused:
+        frs = [mframe.FusedFrame(scene, desc, W, H, spp=spp, band=a.band, rank=rank, world=world, jitter=spp > 1, seed=168,
+                                 flags=flags, rgb=g.local if g is not None and len(bands) else None, tiled=tiled,
+                                 any_shadow=a.any_shadow) for g in (gathers or [None])]
+    else:
+        frs = [mframe.FrameRenderer(scene, desc, W, H, spp=spp, bands=bands, jitter=spp > 1, seed=168, flags=flags,
+                                    rgb=g.local if g is not None and len(bands) else None, tiled=tiled)
+               for g in (gathers or [None])]
+        for fr in frs[:1]:
+            fr.generate(stream)
+        if len(frs) > 1:        # the second renderer shares the first one's ray / hit buffers, only its rgb target differs
+            for k in ("d_rays", "d_hits", "d_shadow_rays", "d_shadow_hits", "d_src", "d_count"):
+                setattr(frs[1], k, getattr(frs[0], k))
+    fr0 = frs[0]
     torch.cuda.synchronize()
+    frame_no = [0]
 
     def one_step(events=None):
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if events is not None else None
+        k = frame_no[0] % len(frs)
+        frame_no[0] += 1
+        fr, g = frs[k], (gathers[k] if gathers else None)
+        if g is not None:
+            g.wait()                    # this buffer's previous gather (two frames ago) has left it
         if fr.n:
-            if e: e[0].record(stream)
-            fr.trace_primary(stream)
-            if e: e[1].record(stream)
-            fr.make_shadow_rays(stream)
-            if e: e[2].record(stream)
-            fr.trace_shadow(stream, a.any_shadow)
-            if e: e[3].record(stream)
-        if gather is not None:
-            gather.wait()               # frame k-1 has left the send buffer (and, on rank 0, is de-interleaved)
-        if fr.n:
-            fr.shade(stream)
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if events is not None else None
+            if fused:
+                if e: e[0].record(stream)
+                fr.step(stream)
+                if e: e[1].record(stream)
+            else:
+                if e: e[0].record(stream)
+                fr.trace_primary(stream)
+                if e: e[1].record(stream)
+                fr.make_shadow_rays(stream)
+                if e: e[2].record(stream)
+                fr.trace_shadow(stream, a.any_shadow)
+                if e: e[3].record(stream)
+                fr.shade(stream)
             if e: events.append(e)
-        if gather is not None:
-            gather.start()
+        if g is not None:
+            g.start()
 
-    if gather is not None:
+    if a.pmc_leg:
+        # the profiled child of live_pmc(): the same frame, one untimed + two counted launches, nothing else
+        for _ in range(3):
+            one_step()
+        torch.cuda.synchronize()
+        print("PMC_LEG samples_per_launch=%d" % fr0.n)
+        return
+
+    if gathers is not None:
         # RCCL sets up its point-to-point channels at the first send/recv between a pair of ranks: do that here, so
-        # that a run with --warmup 0 does not time connection set-up (the buffer holds no frame yet; nothing reads it)
-        gather.start()
-        gather.wait()
+        # that a run with --warmup 0 does not time connection set-up (the buffers hold no frame yet; nothing reads them)
+        for g in gathers:
+            g.start()
+            g.wait()
     for _ in range(a.warmup):
         one_step()
-    if gather is not None:
-        gather.wait()
+    if gathers is not None:
+        for g in gathers:
+            g.wait()
     torch.cuda.synchronize()
+    if fused:
+        for fr in frs:
+            fr.d_counts.zero_()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -212,15 +329,20 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         one_step(events)
-    if gather is not None:
-        gather.wait()                   # the last frame's gather and de-interleave belong to the timed region
+    if gathers is not None:
+        for g in gathers:
+            g.wait()                    # the last frames' gathers and de-interleaves belong to the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    n_p, n_s = fr.ray_counts()
+    if fused:
+        c = sum(fr.d_counts.cpu().numpy().astype(np.int64) for fr in frs)
+        n_p, n_s = int(c[0]) // max(a.steps, 1), int(c[1]) // max(a.steps, 1)
+    else:
+        n_p, n_s = fr0.ray_counts()
     tot = torch.tensor([float(n_p + n_s), elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
         rays_all = tot[0:1].clone()
@@ -231,16 +353,87 @@ def main():
     else:
         rays_per_step = float(n_p + n_s)
 
-    # dominant kernel (trace_kernel): live HIP-event durations of its launches on rank 0's stream
-    ms_p = [e[0].elapsed_time(e[1]) for e in events]
-    ms_s = [e[2].elapsed_time(e[3]) for e in events]
-    trace_ms = sum(ms_p) + sum(ms_s)
-    alg_bytes = a.steps * (n_p * Bp + n_s * Bs)
-    achieved = alg_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
-
     if rank == 0:
         workload = "%s %dx%d %dspp primary+shadow" % (label, W, H, spp)
-        traffic = load_traffic(workload)
+        # ---- dominant kernel: live HIP-event durations of its launches on rank 0's stream
+        if fused:
+            ms_k = [e[0].elapsed_time(e[1]) for e in events]
+            kernel_name, launches_per_step = "frame_kernel (eye ray + primary trace + shadow trace + shade, one launch per step)", 1
+            avg_ms = {"frame": round(sum(ms_k) / max(len(ms_k), 1), 4)}
+            kernel_ms = sum(ms_k)
+        else:
+            ms_p = [e[0].elapsed_time(e[1]) for e in events]
+            ms_s = [e[2].elapsed_time(e[3]) for e in events]
+            kernel_name, launches_per_step = "trace_kernel (primary + shadow launches)", 2
+            avg_ms = {"primary": round(sum(ms_p) / max(len(ms_p), 1), 4), "shadow": round(sum(ms_s) / max(len(ms_s), 1), 4)}
+            kernel_ms = sum(ms_p) + sum(ms_s)
+        kernel_s_per_step = kernel_ms * 1e-3 / max(a.steps, 1)
+        samples_rank0 = fr0.n
+
+        # ---- SQ / TCC counters of that kernel: live rocprofv3 passes over this workload, else the committed profile
+        pmc, pmc_source, pmc_note = None, None, None
+        if fused and world == 1 and not a.no_pmc:
+            leg = ["--pmc-leg", "--no-cpu-baseline", "--no-pmc", "--scene", a.scene, "--width", str(W), "--height", str(H),
+                   "--spp", str(spp), "--steps", "2", "--warmup", "1"] + (["--product"] if a.product else []) + \
+                  (["--incoherent"] if a.incoherent else []) + (["--any-shadow"] if a.any_shadow else []) + \
+                  (["--image-order"] if a.image_order else [])
+            pmc, pmc_note = live_pmc(leg, "frame_kernel")
+            if pmc:
+                pmc_source = "live: rocprofv3 --pmc passes over this workload, started by this run"
+                per = {k: v / samples_rank0 for k, v in pmc.items() if not k.startswith("dispatches_")}
+                rec = {"workload": workload, "kernel": "frame_kernel", "samples_per_launch": samples_rank0,
+                       "counters_per_launch": {k: v for k, v in pmc.items()}, "per_sample": per,
+                       "flags": {"product": a.product, "incoherent": a.incoherent, "any_shadow": a.any_shadow, "tiled": tiled}}
+                try:
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    json.dump(rec, open(os.path.join(ROOT, "gpurun_out", "r02_bench_pmc.json"), "w"), indent=1)
+                except Exception:
+                    pass
+        if pmc is None:
+            rec = committed_pmc(workload)
+            if rec:
+                pmc = {k: v * samples_rank0 for k, v in rec["per_sample"].items()}
+                pmc_source = "committed: profiles/r02_bench_pmc.json (%s), scaled per sample to this launch" % rec.get("workload")
+        roof = {"bound": "valu_issue", "kernel": kernel_name, "peak": round(VALU_PEAK_GINSTR, 1), "unit": "Ginstr/s",
+                "peak_definition": "%d SIMD-32 x %.1f GHz / 2 cycles per wave64 VALU instruction" % (N_SIMD, CLOCK_GHZ),
+                "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step, "pmc_source": pmc_source}
+        if pmc_note:
+            roof["pmc_note"] = pmc_note
+        if pmc and pmc.get("SQ_INSTS_VALU"):
+            achieved = pmc["SQ_INSTS_VALU"] / kernel_s_per_step / 1e9
+            roof.update({"achieved": round(achieved, 1), "frac": round(achieved / VALU_PEAK_GINSTR, 4),
+                         "valu_insts_per_launch": round(pmc["SQ_INSTS_VALU"]),
+                         "valu_insts_per_64_samples": round(pmc["SQ_INSTS_VALU"] * 64.0 / samples_rank0, 1)})
+            if pmc.get("SQ_THREAD_CYCLES_VALU"):
+                roof["lane_utilisation"] = round(pmc["SQ_THREAD_CYCLES_VALU"] / pmc["SQ_INSTS_VALU"] / 64.0, 4)
+            if pmc.get("SQ_BUSY_CYCLES"):
+                # the profiler's own clock: SQ_BUSY_CYCLES / 32 = kernel cycles under the counter pass
+                roof["frac_at_profiled_clock"] = round(pmc["SQ_INSTS_VALU"] * 2.0 / (N_SIMD * pmc["SQ_BUSY_CYCLES"] / 32.0), 4)
+            if pmc.get("SQ_WAVE_CYCLES"):
+                wc = pmc["SQ_WAVE_CYCLES"]
+                roof["wave_cycle_split"] = {"waiting": round(pmc.get("SQ_WAIT_ANY", 0) / wc, 3),
+                                            "issue_stalled": round(pmc.get("SQ_WAIT_INST_ANY", 0) / wc, 3)}
+        else:
+            roof.update({"achieved": None, "frac": None})
+        # HBM: measured traffic (guide: FETCH_SIZE is in KiB and reports half of a wide streaming read on gfx950 -> x2;
+        # WRITE_SIZE exact) and the nominal algorithmic figure of SURVEY.md 8(d)
+        traffic = None
+        if pmc and pmc.get("FETCH_SIZE") is not None and pmc.get("WRITE_SIZE") is not None:
+            traffic = (pmc["FETCH_SIZE"] * 2.0 + pmc["WRITE_SIZE"]) * 1024.0
+        roof["traffic"] = round(traffic) if traffic is not None else None
+        (Vp, Tp), (Vs, Ts), _ = reference_counts(scene, (desc, W, H, bands, 168), desc["light"])
+        Bp, Bs = algorithmic_bytes_per_ray(Vp, Tp), algorithmic_bytes_per_ray(Vs, Ts)
+        nominal = (n_p * Bp + n_s * Bs) / kernel_s_per_step / 1e9 if kernel_s_per_step > 0 else 0.0
+        roof["hbm"] = {
+            "peak_GBps": HBM_PEAK_GBPS,
+            "nominal_algorithmic_GBps": round(nominal, 1),
+            "nominal_label": "SURVEY 8(d) bytes (32+16+24V+36T per ray, reference-counted V/T) over kernel time: the 5 MB scene "
+                             "is cache-resident, so this is NOT a bound and may exceed the HBM peak",
+            "algorithmic_bytes_per_ray": {"primary": round(Bp, 1), "shadow": round(Bs, 1)},
+            "reference_visits_per_ray": {"primary": [round(Vp, 3), round(Tp, 3)], "shadow": [round(Vs, 3), round(Ts, 3)]},
+            "measured_GBps": round(traffic / kernel_s_per_step / 1e9, 1) if traffic is not None else None,
+            "hbm_measured_frac": round(traffic / kernel_s_per_step / 1e9 / HBM_PEAK_GBPS, 4) if traffic is not None else None,
+        }
         out = {
             "metric": "Mrays/s (primary+shadow)",
             "value": round(rays_per_step * a.steps / elapsed / 1e6, 2),
@@ -257,34 +450,26 @@ def main():
             "config": {
                 "workload": workload,
                 "scene_triangles": int(info.n_triangles), "bvh_nodes": int(info.n_nodes),
-                "rays_per_step": int(rays_per_step), "math": "fast" if a.fast else (
-                    "exact triangle test, slab distances as products with the rounded 1/d (MR_MATH_PRODUCT)" if a.product else
-                    "exact: every quotient of the reference's slab and triangle tests, bit for bit"),
+                "rays_per_step": int(rays_per_step),
+                "step": "mr_render_direct: eye rays generated, traced, shadow rays built and traced, samples shaded in one "
+                        "launch" if fused else "batched: mr_trace -> mr_gen_shadow_rays -> mr_trace_indirect -> mr_shade_direct "
+                        "over resident rays",
+                "math": "exact triangle test, slab distances as products with the rounded 1/d (MR_MATH_PRODUCT)" if a.product else
+                        "exact: every quotient of the reference's slab and triangle tests, bit for bit",
+                "control_flow": "voting (MR_TRACE_INCOHERENT)" if a.incoherent else "while-while",
                 "shadow_query": "any-hit" if a.any_shadow else "closest-hit (as Phong.cpp:97)",
-                "ray_order": "tiled (mr_gen_eye_rays_tiled)" if fr.tiled else "image order",
+                "ray_order": "tiled" if (fr0.tiled if hasattr(fr0, "tiled") else False) else "image order",
                 "parallelism": "image rows in interleaved bands of %d over %d GPU(s), scene replicated, 1 RCCL gather of the framebuffer" % (a.band, world),
-                "resident_bytes_per_gpu": int(fr.bytes_resident() + info.device_bytes),
+                "resident_bytes_per_gpu": int(sum(fr.bytes_resident() for fr in (frs if fused else frs[:1])) + info.device_bytes),
                 "bvh_build_s": round(t_build, 3),
                 # context only (other scene size, unstated CPU): the reference's write-up, sponza 512x512 1 spp with
                 # shadows, 524 288 rays in 0.166750 s (writeup/A2/Readme.tex:83,98) -- not this workload, so no vs_baseline
                 "reference_writeup_mrays_s_sponza_512x512": 3.14,
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "trace_kernel (primary + shadow launches, rank 0)",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": traffic.get("hbm_bytes_per_launch") if traffic else None,
-                "algorithmic_bytes_per_ray": {"primary": round(Bp, 1), "shadow": round(Bs, 1)},
-                "reference_visits_per_ray": {"primary": [round(Vp, 3), round(Tp, 3)], "shadow": [round(Vs, 3), round(Ts, 3)]},
-                "avg_launch_ms": {"primary": round(sum(ms_p) / len(ms_p), 4), "shadow": round(sum(ms_s) / len(ms_s), 4)},
-                "note": "achieved = reference-counted node/triangle bytes over kernel time; the 5 MB scene is "
-                        "L2/Infinity-Cache resident, so achieved may exceed what HBM itself delivers (see traffic)",
-            },
+            "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:
-            threads = min(len(os.sched_getaffinity(0)), int(os.environ.get("MIRO_CPU_THREADS", "16")))
-            out["cpu_baseline"] = cpu_baseline(desc, label, W, H, a.cpu_spp, threads)
+            out["cpu_baseline"] = cpu_baseline(desc, label, W, H, a.cpu_spp)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

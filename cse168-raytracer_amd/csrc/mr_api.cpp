@@ -604,6 +604,22 @@ mr_status mr_shade_direct(mr_scene *s, const mr_ray *d_rays, const mr_hit *d_hit
                         d_rgb, static_cast<hipStream_t>(stream));
 }
 
+mr_status mr_render_direct(mr_scene *s, const mr_frame_desc *frame, float *d_rgb, mr_hit *d_hits, mr_hit *d_shadow_hits,
+                           uint64_t *d_counts, void *stream) {
+    mr_status st = require_device(s);
+    if (st != MR_OK) return st;
+    if (!frame || !d_rgb) return fail(MR_ERR_INVALID, "NULL argument");
+    if (frame->W == 0 || frame->H == 0) return fail(MR_ERR_INVALID, "empty image");
+    if ((reinterpret_cast<uintptr_t>(d_hits) & 15) || (reinterpret_cast<uintptr_t>(d_shadow_hits) & 15) ||
+        (reinterpret_cast<uintptr_t>(d_counts) & 7) || (reinterpret_cast<uintptr_t>(d_rgb) & 3))
+        return fail(MR_ERR_INVALID, "hit buffers must be 16-byte aligned, counters 8-byte aligned");
+    mr_frame_desc fd = *frame;
+    if (fd.band_world <= 1) { fd.band_world = 1; fd.band_rank = 0; if (fd.band_rows == 0) fd.band_rows = 1; }
+    MR_HIP_CHECK(hipSetDevice(s->device));
+    return launch_frame(s->dev, fd, d_rgb, d_hits, d_shadow_hits, reinterpret_cast<unsigned long long *>(d_counts),
+                        static_cast<hipStream_t>(stream));
+}
+
 mr_status mr_scene_set_materials(mr_scene *s, const mr_material *mats, uint32_t n_mats, const uint32_t *prim_material) {
     if (!s || !mats || n_mats == 0) return fail(MR_ERR_INVALID, "NULL argument or no materials");
     const uint32_t nt = s->mesh.n_triangles();

@@ -1,0 +1,213 @@
+// mr_frame.hip -- the reference's per-pixel loop (Scene::raytraceImage, Scene.cpp:112-141) as ONE launch:
+//
+//   Camera::eyeRay (Camera.cpp:104-161)  ->  Scene::trace (Scene.cpp:278)  ->  Phong::shade's shadow ray towards the
+//   point light (Phong.cpp:80-97)  ->  Scene::trace (Phong.cpp:97)  ->  Phong::shade's direct term (Phong.cpp:116-156)
+//   ->  mean over the pixel's samples (Scene.cpp:126-139)
+//
+// One sample per lane.  The primary ray is generated in registers from the camera frame, traced, the shadow ray is
+// built from the hit still in registers and traced by the same lane with the same LDS stack, the sample is shaded and
+// the pixel's samples meet in an xor-butterfly.  No ray buffer exists: the batched pipeline (mr_gen_eye_rays ->
+// mr_trace -> mr_gen_shadow_rays -> mr_trace_indirect -> mr_shade_direct) keeps 100 bytes per sample resident and moves
+// 148 bytes per sample through HBM; this kernel writes 12 bytes per PIXEL (plus, on request, the two 16-byte hit
+// records per sample, which is what parity tests compare).
+//
+// Every piece is the shared definition the batched kernels use (mr_eye.h, mr_traverse.h, mr_surface.h, mr_phong.h), so
+// rays, hit records and pixels are the same bits as the batched pipeline's -- tests/test_frame.py compares them.
+#include <hip/hip_runtime.h>
+
+#include "mr_eye.h"
+#include "mr_internal.h"
+#include "mr_phong.h"
+#include "mr_surface.h"
+#include "mr_tile.h"
+#include "mr_traverse.h"
+
+namespace mr {
+namespace {
+
+struct FrameArgs {
+    EyeFrame eye;
+    TraceParams tp;              // scene arrays, root box; rays / hits / n unused
+    SurfacePtrs m;
+    DirectLight lt;
+    mr_hit *hits;                // optional: primary hit record of sample k
+    mr_hit *shadow_hits;         // optional: record of sample k's shadow ray (prim = MR_MISS, t = 0 when it has none)
+    float *rgb;                  // [rows * W][3], window rows in band order, image order inside a row
+    unsigned long long *counts;  // optional: [0] += primary rays, [1] += shadow rays traced by this launch
+};
+
+// VAR: the traversal variant of trace_ray (mr_traverse.h) for both rays; ANY_SHADOW: the shadow ray stops at its first
+// accepted hit (opaque scenes: same occlusion flag, hence the same picture).
+template <int VAR, bool ANY_SHADOW>
+__global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(7, 8))) void frame_kernel(FrameArgs a) {
+    extern __shared__ int s_stack[];                  // [stack_depth][kTraceBlock]
+    __shared__ unsigned s_shadow_rays[kTraceBlock / 64];
+    const int tid = threadIdx.x;
+    const unsigned long long stride = (unsigned long long)gridDim.x * kTraceBlock;
+    const unsigned long long n = a.eye.n, n_round = (n + 63ull) & ~63ull;
+    constexpr bool kObj = (VAR & 32) != 0;
+    const uint32_t spp = a.eye.spp;
+    const float inv_spp = 1.0f / (float)spp;
+    Stats st = {0ull, 0ull};
+    unsigned my_shadow_rays = 0;
+
+    for (unsigned long long idx = (unsigned long long)blockIdx.x * kTraceBlock + tid; idx < n_round; idx += stride) {
+        const bool live = idx < n;
+        uint32_t x = 0, row = 0, y = 0, sm = 0;
+        float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(1.f, 1.f, 1.f, -1.f);
+        if (live) {
+            eye_sample_of(a.eye, idx, x, row, y, sm);
+            eye_ray_of(a.eye, x, y, sm, ra, rb);
+        }
+        // ---- primary ray
+        mr_hit h;
+        {
+            RayRegs r;
+            ray_setup(r, ra, rb);
+            Lane L;
+            int plane_hit;
+            trace_ray<true, false, false, VAR>(a.tp, r, rb.w, live, L, plane_hit, s_stack, tid, st);
+            h = make_hit<kObj>(a.tp, L, plane_hit, rb.w);
+        }
+        if (a.hits && live) reinterpret_cast<float4 *>(a.hits)[idx] = *reinterpret_cast<const float4 *>(&h);
+
+        // ---- shadow ray from the hit in registers (Phong.cpp:80-97).  The sample's colour is computed BEFORE the
+        // shadow ray is traced and zeroed afterwards if the light is occluded (Phong.cpp:97-100): only three values
+        // stay live across the second traversal instead of the hit point, the normal and the eye direction, which
+        // keeps the kernel at the register count of the plain trace kernel.
+        const bool hit = live && h.prim != MR_MISS;
+        float c[3] = {0.f, 0.f, 0.f};
+        if (live && !hit) { c[0] = a.lt.bg[0]; c[1] = a.lt.bg[1]; c[2] = a.lt.bg[2]; }         // Scene.cpp:340
+        float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = make_float4(1.f, 1.f, 1.f, -1.f);
+        if (hit) {
+            float P[3], N[3];
+            surface_od<true>(a.m, ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, h.t, h.prim, h.beta, h.gamma, P, N);
+            shadow_ray_of(P, a.lt.L[0], a.lt.L[1], a.lt.L[2], sa, sb);
+            phong_direct(a.lt, P, N, rb.x, rb.y, rb.z, c);                                      // Phong.cpp:116-156
+            my_shadow_rays++;
+        }
+        bool occluded;
+        {
+            RayRegs r;
+            ray_setup(r, sa, sb);
+            Lane L;
+            int plane_hit;
+            trace_ray<true, ANY_SHADOW, false, VAR>(a.tp, r, sb.w, hit, L, plane_hit, s_stack, tid, st);
+            mr_hit hs = make_hit<kObj>(a.tp, L, plane_hit, sb.w);
+            if (!hit) { hs.t = 0.0f; hs.prim = MR_MISS; hs.beta = 0.0f; hs.gamma = 0.0f; }
+            occluded = hs.prim != MR_MISS;
+            if (a.shadow_hits && live) reinterpret_cast<float4 *>(a.shadow_hits)[idx] = *reinterpret_cast<const float4 *>(&hs);
+        }
+        if (occluded) { c[0] = 0.f; c[1] = 0.f; c[2] = 0.f; }
+        // the pixel's mean (Scene.cpp:126-139)
+        // spp is a power of two <= 64 (checked by the host): a pixel's samples are `spp` consecutive, aligned lanes; the
+        // summation tree depends on the sample index only -- the same tree as shade_samples_kernel's
+        for (uint32_t off = 1; off < spp; off <<= 1) {
+            c[0] += __shfl_xor(c[0], (int)off, 64);
+            c[1] += __shfl_xor(c[1], (int)off, 64);
+            c[2] += __shfl_xor(c[2], (int)off, 64);
+        }
+        if (live) eye_sample_of(a.eye, idx, x, row, y, sm);      // recomputed: cheaper than four live registers
+        if (live && sm == 0) {
+            if (spp > 1) { c[0] *= inv_spp; c[1] *= inv_spp; c[2] *= inv_spp; }
+            float *o = a.rgb + 3 * ((size_t)row * a.eye.W + x);
+            o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
+        }
+    }
+
+    if (a.counts) {
+        // rays traced: one atomic pair per workgroup
+        unsigned w = my_shadow_rays;
+        for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off, 64);
+        if ((tid & 63) == 0) s_shadow_rays[tid >> 6] = w;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long tot = 0;
+            for (int k = 0; k < kTraceBlock / 64; k++) tot += s_shadow_rays[k];
+            unsigned long long mine = 0;     // primary rays of this workgroup's strides
+            for (unsigned long long base = (unsigned long long)blockIdx.x * kTraceBlock; base < n; base += stride)
+                mine += n - base < (unsigned long long)kTraceBlock ? n - base : (unsigned long long)kTraceBlock;
+            atomicAdd(&a.counts[0], mine);
+            if (tot) atomicAdd(&a.counts[1], tot);
+        }
+    }
+}
+
+template <int VAR, bool ANY_SHADOW>
+mr_status launch_frame_t(const FrameArgs &a, hipStream_t stream) {
+    const size_t lds = (size_t)a.tp.stack_depth * kTraceBlock * sizeof(int);
+    if (lds > 150 * 1024) return fail(MR_ERR_INVALID, "traversal stack of depth %d does not fit in LDS", a.tp.stack_depth);
+    if (lds > 48 * 1024)
+        MR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&frame_kernel<VAR, ANY_SHADOW>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    unsigned long long blocks = (a.eye.n + kTraceBlock - 1) / kTraceBlock;
+    if (blocks > (unsigned long long)kTraceGridCap) blocks = kTraceGridCap;
+    hipLaunchKernelGGL((frame_kernel<VAR, ANY_SHADOW>), dim3((unsigned)blocks), dim3(kTraceBlock), lds, stream, a);
+    MR_HIP_CHECK(hipGetLastError());
+    return MR_OK;
+}
+
+}  // namespace
+
+mr_status launch_frame(const DeviceScene &ds, const mr_frame_desc &fd, float *d_rgb, mr_hit *d_hits, mr_hit *d_shadow_hits,
+                       unsigned long long *d_counts, hipStream_t stream) {
+    FrameArgs a;
+    const uint32_t spp = fd.spp;
+    if (spp == 0 || spp > 64 || (spp & (spp - 1)))
+        return fail(MR_ERR_INVALID, "mr_render_direct: spp must be a power of two <= 64 (got %u); use the batched pipeline", spp);
+    if (fd.band_world == 0 || fd.band_rank >= fd.band_world || fd.band_rows == 0)
+        return fail(MR_ERR_INVALID, "mr_render_direct: bad band description (%u rows, rank %u of %u)", fd.band_rows, fd.band_rank, fd.band_world);
+    // rows of this window
+    uint32_t rows = 0;
+    if (fd.band_world == 1) {
+        if (fd.y1 > fd.H || fd.y0 > fd.y1) return fail(MR_ERR_INVALID, "mr_render_direct: rows [%u,%u) outside the image", fd.y0, fd.y1);
+        rows = fd.y1 - fd.y0;
+    } else {
+        const uint32_t nb = (fd.H + fd.band_rows - 1) / fd.band_rows;
+        for (uint32_t b = fd.band_rank; b < nb; b += fd.band_world) {
+            const uint32_t y0 = b * fd.band_rows, y1 = y0 + fd.band_rows < fd.H ? y0 + fd.band_rows : fd.H;
+            rows += y1 - y0;
+        }
+    }
+    a.eye = make_eye_frame(fd.camera, fd.W, fd.H, fd.band_world == 1 ? fd.y0 : 0, fd.band_world == 1 ? fd.y1 : rows, spp, fd.jitter, fd.seed,
+                           fd.tiled != 0);
+    a.eye.rows = rows;
+    a.eye.n = (unsigned long long)rows * fd.W * spp;
+    if (fd.band_world > 1) {
+        a.eye.y0 = 0; a.eye.band_rows = fd.band_rows; a.eye.band_rank = fd.band_rank; a.eye.band_world = fd.band_world;
+        // a ragged last band (H not a multiple of band_rows) only ever is the LAST window row group of its owner, so the
+        // row -> image row formula of eye_sample_of holds for it as well
+    }
+    if (a.eye.n == 0) return MR_OK;
+    if (a.eye.n >= (1ull << 32) * spp) return fail(MR_ERR_INVALID, "mr_render_direct: window too large");
+    TraceParams &p = a.tp;
+    p.nodes = ds.nodes; p.tris = ds.tris; p.tri_prim = ds.tri_prim; p.leaf_cnt_ext = ds.leaf_cnt_ext;
+    for (int c = 0; c < 3; c++) { p.root_lo[c] = ds.root_lo[c]; p.root_hi[c] = ds.root_hi[c]; }
+    p.root_ref = ds.root_ref;
+    p.stack_depth = (int32_t)ds.stack_depth;
+    p.rays = nullptr; p.hits = nullptr; p.n = a.eye.n; p.n_dev = nullptr; p.stats = nullptr;
+    p.planes = ds.planes; p.n_planes = ds.n_planes; p.n_spheres = ds.n_spheres;
+    p.work_counter = nullptr;
+    a.m = surface_ptrs(ds);
+    for (int c = 0; c < 3; c++) {
+        a.lt.L[c] = fd.light.position[c]; a.lt.color[c] = fd.light.color[c]; a.lt.diffuse[c] = fd.diffuse[c]; a.lt.bg[c] = 0.0f;
+    }
+    a.lt.wattage = fd.light.wattage;
+    a.hits = d_hits; a.shadow_hits = d_shadow_hits; a.rgb = d_rgb; a.counts = d_counts;
+
+    const bool any = fd.flags & MR_TRACE_ANY, product = fd.flags & MR_MATH_PRODUCT, vote = fd.flags & MR_TRACE_INCOHERENT;
+    if (fd.flags & ~(uint32_t)(MR_TRACE_ANY | MR_MATH_PRODUCT | MR_TRACE_INCOHERENT))
+        return fail(MR_ERR_INVALID, "mr_render_direct: flags may hold MR_TRACE_ANY, MR_MATH_PRODUCT, MR_TRACE_INCOHERENT only");
+    if (ds.n_planes || ds.n_spheres) {
+        if (product) return any ? launch_frame_t<43, true>(a, stream) : launch_frame_t<43, false>(a, stream);
+        return any ? launch_frame_t<58, true>(a, stream) : launch_frame_t<58, false>(a, stream);
+    }
+    if (vote) {
+        if (product) return any ? launch_frame_t<73, true>(a, stream) : launch_frame_t<73, false>(a, stream);
+        return any ? launch_frame_t<88, true>(a, stream) : launch_frame_t<88, false>(a, stream);
+    }
+    if (product) return any ? launch_frame_t<11, true>(a, stream) : launch_frame_t<11, false>(a, stream);
+    return any ? launch_frame_t<26, true>(a, stream) : launch_frame_t<26, false>(a, stream);
+}
+
+}  // namespace mr

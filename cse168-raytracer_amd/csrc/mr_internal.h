@@ -148,6 +148,10 @@ mr_status launch_tonemap(const float *d_rgb, unsigned long long n_values, uint8_
 mr_status launch_untile(const float *d_slots, float *d_image, uint32_t W, uint32_t rows, uint32_t spp, uint32_t channels,
                         hipStream_t stream);
 
+// the fused direct-light frame (mr_frame.hip)
+mr_status launch_frame(const DeviceScene &ds, const mr_frame_desc &fd, float *d_rgb, mr_hit *d_hits, mr_hit *d_shadow_hits,
+                       unsigned long long *d_counts, hipStream_t stream);
+
 mr_status launch_shade_accumulate(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
                                   const uint32_t *d_pixels, unsigned long long n, const mr_ray *d_shadow_rays,
                                   const mr_hit *d_shadow_hits, const uint32_t *d_shadow_src,

@@ -21,6 +21,7 @@
 #include "mr_internal.h"
 #include "mr_surface.h"
 #include "mr_eye.h"
+#include "mr_phong.h"
 #include "mr_tile.h"
 #include "mr_traverse.h"
 
@@ -249,14 +250,8 @@ __global__ __launch_bounds__(kBlock) void shadow_rays_kernel(SurfacePtrs m, cons
             const unsigned long long slot = wave_base + prefix[it];
             float P[3];
             surface<false>(m, rays, k, h[it].x, __float_as_uint(h[it].y), h[it].z, h[it].w, P, nullptr);
-            const float Px = P[0], Py = P[1], Pz = P[2];
-            float lx = Lx - Px, ly = Ly - Py, lz = Lz - Pz;           // PointLight::getLightDirection
-            const float falloff = (lx * lx + ly * ly) + lz * lz;
-            const float len = sqrtf(falloff);
-            const float inv = 1.0f / len;                              // l /= sqrt(falloff)
-            lx *= inv; ly *= inv; lz *= inv;
-            float4 a = make_float4(Px + lx * kEps, Py + ly * kEps, Pz + lz * kEps, 0.0f);
-            float4 b = make_float4(lx, ly, lz, len);
+            float4 a, b;
+            shadow_ray_of(P, Lx, Ly, Lz, a, b);
             reinterpret_cast<float4 *>(out)[2 * slot] = a;
             reinterpret_cast<float4 *>(out)[2 * slot + 1] = b;
             if (src) src[slot] = (uint32_t)k;

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mr_internal.h"
+#include "mr_phong.h"
 #include "mr_surface.h"
 #include "mr_tile.h"
 
@@ -17,7 +18,6 @@ namespace mr {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr float kPI = 3.1415926535897932384626433832795028841972f;   // Miro.h:10
 
 __global__ __launch_bounds__(kBlock) void occlusion_scatter_kernel(const mr_hit *shadow_hits, const uint32_t *src,
                                                                    const unsigned long long *count,
@@ -34,8 +34,7 @@ struct ShadeArgs {
     const mr_ray *rays;
     const mr_hit *hits;
     const uint8_t *occluded;
-    float L[3], color[3], diffuse[3], bg[3];
-    float wattage;
+    DirectLight lt;
     uint32_t spp;
     unsigned long long n_pixels;
     float *rgb;
@@ -44,37 +43,13 @@ struct ShadeArgs {
 __device__ __forceinline__ void shade_sample(const ShadeArgs &a, unsigned long long k, float out[3]) {
     const float4 h = reinterpret_cast<const float4 *>(a.hits)[k];
     const uint32_t prim = __float_as_uint(h.y);
-    if (prim == MR_MISS) { out[0] = a.bg[0]; out[1] = a.bg[1]; out[2] = a.bg[2]; return; }   // Scene.cpp:340
+    if (prim == MR_MISS) { out[0] = a.lt.bg[0]; out[1] = a.lt.bg[1]; out[2] = a.lt.bg[2]; return; }   // Scene.cpp:340
     out[0] = out[1] = out[2] = 0.0f;
     if (a.occluded[k]) return;                                                              // Phong.cpp:97-100
     float P[3], N[3];
     surface<true>(a.m, a.rays, k, h.x, prim, h.z, h.w, P, N);                               // HitInfo::P, ::N
-    {   // Scene.cpp:262 -- N.normalize()
-        const float inv = 1.0f / sqrtf((N[0] * N[0] + N[1] * N[1]) + N[2] * N[2]);
-        N[0] *= inv; N[1] *= inv; N[2] *= inv;
-    }
-    float l[3] = {a.L[0] - P[0], a.L[1] - P[1], a.L[2] - P[2]};
-    const float falloff = (l[0] * l[0] + l[1] * l[1]) + l[2] * l[2];
-    {
-        const float inv = 1.0f / sqrtf(falloff);
-        l[0] *= inv; l[1] *= inv; l[2] *= inv;
-    }
-    const float nDotL = (N[0] * l[0] + N[1] * l[1]) + N[2] * l[2];
-    const float f2 = 1.0f / (falloff * 4.0f * kPI * kPI);                                   // Phong.cpp:140
-    const float diff = fmaxf(0.0f, nDotL * f2 * a.wattage);
-    for (int c = 0; c < 3; c++) out[c] = a.color[c] * (diff * a.diffuse[c] * a.diffuse[c]);  // :146
-    // specular highlight (:149-156); Phong's default shininess 1 < infinity
-    const float lDotN = (l[0] * N[0] + l[1] * N[1]) + l[2] * N[2];
     const float4 rb = reinterpret_cast<const float4 *>(a.rays)[2 * k + 1];
-    float eDotr = 0.0f;
-    {
-        const float two = 2 * lDotN;
-        const float rx = -l[0] + two * N[0], ry = -l[1] + two * N[1], rz = -l[2] + two * N[2];
-        eDotr = (-rb.x * rx + -rb.y * ry) + -rb.z * rz;
-    }
-    eDotr = powf(fmaxf(0.0f, fminf(1.0f, eDotr)), 500.0f);
-    const float highlights = fmaxf(0.0f, eDotr * f2 * a.wattage);
-    out[0] += highlights; out[1] += highlights; out[2] += highlights;
+    phong_direct(a.lt, P, N, rb.x, rb.y, rb.z, out);
 }
 
 // one thread per pixel, samples summed in order (bitwise reproducible, independent of the grid)
@@ -201,8 +176,8 @@ mr_status launch_shade(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit
     ShadeArgs a;
     a.m = surface_ptrs(ds);
     a.rays = d_rays; a.hits = d_hits; a.occluded = d_occluded;
-    for (int c = 0; c < 3; c++) { a.L[c] = light.position[c]; a.color[c] = light.color[c]; a.diffuse[c] = diffuse[c]; a.bg[c] = 0.0f; }
-    a.wattage = light.wattage;
+    for (int c = 0; c < 3; c++) { a.lt.L[c] = light.position[c]; a.lt.color[c] = light.color[c]; a.lt.diffuse[c] = diffuse[c]; a.lt.bg[c] = 0.0f; }
+    a.lt.wattage = light.wattage;
     a.spp = spp;
     a.n_pixels = n / spp;
     a.rgb = d_rgb;

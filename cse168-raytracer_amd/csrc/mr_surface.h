@@ -27,14 +27,13 @@ inline SurfacePtrs surface_ptrs(const DeviceScene &ds) {
     return m;
 }
 
-// rays may be nullptr for triangle-only scenes (the host checks); k = index of the hit's ray
+// The hit's ray given in registers (o, d): used by the fused frame kernel, and by surface() below once it has
+// fetched the ray.  o / d are read only for spheres and planes.
 template <bool WANT_N>
-__device__ __forceinline__ void surface(const SurfacePtrs &m, const mr_ray *rays, unsigned long long k, float t,
-                                        uint32_t prim, float beta, float gamma, float P[3], float N[3]) {
+__device__ __forceinline__ void surface_od(const SurfacePtrs &m, float ox, float oy, float oz, float dx, float dy, float dz,
+                                           float t, uint32_t prim, float beta, float gamma, float P[3], float N[3]) {
     if ((m.planes && (prim & kPlaneBit)) || (m.spheres && m.vi[3 * (size_t)prim] == kSphereSlot)) {
-        const float4 ra = reinterpret_cast<const float4 *>(rays)[2 * k];
-        const float4 rb = reinterpret_cast<const float4 *>(rays)[2 * k + 1];
-        P[0] = ra.x + t * rb.x; P[1] = ra.y + t * rb.y; P[2] = ra.z + t * rb.z;
+        P[0] = ox + t * dx; P[1] = oy + t * dy; P[2] = oz + t * dz;
         if (!WANT_N) return;
         if (prim & kPlaneBit) {
             const float4 pn = m.planes[2 * (size_t)(prim & ~kPlaneBit)];
@@ -59,6 +58,18 @@ __device__ __forceinline__ void surface(const SurfacePtrs &m, const mr_ray *rays
     const float alpha = 1 - beta - gamma;
     for (int c = 0; c < 3; c++)
         N[c] = (alpha * m.n[3 * (size_t)ja + c] + beta * m.n[3 * (size_t)jb + c]) + gamma * m.n[3 * (size_t)jc + c];
+}
+
+// rays may be nullptr for triangle-only scenes (the host checks); k = index of the hit's ray
+template <bool WANT_N>
+__device__ __forceinline__ void surface(const SurfacePtrs &m, const mr_ray *rays, unsigned long long k, float t,
+                                        uint32_t prim, float beta, float gamma, float P[3], float N[3]) {
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((m.planes && (prim & kPlaneBit)) || (m.spheres && m.vi[3 * (size_t)prim] == kSphereSlot)) {
+        ra = reinterpret_cast<const float4 *>(rays)[2 * k];
+        rb = reinterpret_cast<const float4 *>(rays)[2 * k + 1];
+    }
+    surface_od<WANT_N>(m, ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, t, prim, beta, gamma, P, N);
 }
 
 // material id of a hit: planes carry theirs, bounded objects look it up (nullptr table: material 0)

@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "mr_scene_add_sphere", "mr_scene_add_plane",
     "mr_bvh_build", "mr_scene_get_info", "mr_scene_get_mesh", "mr_scene_export_tree",
     "mr_trace", "mr_host_alloc", "mr_host_free", "mr_trace_indirect", "mr_trace_get_stats", "mr_gen_eye_rays", "mr_gen_eye_rays_tiled", "mr_tile_pixel_map", "mr_untile_pixels", "mr_gen_shadow_rays", "mr_hit_attrs",
-    "mr_shade_direct", "mr_tonemap",
+    "mr_shade_direct", "mr_render_direct", "mr_tonemap",
     "mr_scene_set_materials", "mr_shade_accumulate", "mr_gen_secondary_rays",
     "mr_photon_map_create", "mr_photon_map_destroy", "mr_photon_map_store", "mr_photon_map_scale",
     "mr_photon_map_balance", "mr_photon_map_count", "mr_photon_map_export", "mr_irradiance_estimate",
@@ -73,6 +73,14 @@ class Camera(C.Structure):
 
 class Light(C.Structure):
     _fields_ = [("position", C.c_float * 3), ("color", C.c_float * 3), ("wattage", C.c_float)]
+
+
+class FrameDesc(C.Structure):
+    """mr_frame_desc (miro_hip.h): one window of a direct-light frame for mr_render_direct"""
+    _fields_ = [("camera", Camera), ("W", C.c_uint32), ("H", C.c_uint32), ("y0", C.c_uint32), ("y1", C.c_uint32),
+                ("band_rows", C.c_uint32), ("band_rank", C.c_uint32), ("band_world", C.c_uint32),
+                ("spp", C.c_uint32), ("jitter", C.c_uint32), ("seed", C.c_uint32), ("tiled", C.c_uint32),
+                ("flags", C.c_uint32), ("light", Light), ("diffuse", C.c_float * 3), ("reserved", C.c_uint32 * 4)]
 
 
 class Material(C.Structure):
@@ -136,6 +144,7 @@ def load_library(path=None):
     L.mr_scene_add_sphere.argtypes = [vp, f32p, C.c_float, u32p]
     L.mr_scene_add_plane.argtypes = [vp, f32p, f32p, C.c_uint32, u32p]
     L.mr_shade_direct.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, vp, C.POINTER(Light), f32p, C.c_uint32, vp, vp]
+    L.mr_render_direct.argtypes = [vp, C.POINTER(FrameDesc), vp, vp, vp, vp, vp]
     L.mr_tonemap.argtypes = [vp, vp, C.c_uint64, vp, vp]
     L.mr_scene_set_materials.argtypes = [vp, C.POINTER(Material), C.c_uint32, u32p]
     L.mr_shade_accumulate.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, C.POINTER(Light), C.c_uint32, vp, vp]
@@ -373,6 +382,25 @@ class Scene:
         _check(self.L.mr_shade_direct(self.h, d_rays.data_ptr(), d_hits.data_ptr(), n, d_shadow_hits.data_ptr(),
                                       d_shadow_src.data_ptr(), d_shadow_count.data_ptr(), C.byref(lt), _f32p(df), spp,
                                       d_rgb.data_ptr(), _stream_ptr(stream)))
+
+    def render_direct(self, cam, W, H, d_rgb, light_pos, wattage, y0=0, y1=None, bands=None, spp=1, jitter=False, seed=168,
+                      tiled=False, flags=0, color=(1.0, 1.0, 1.0), diffuse=(1.0, 1.0, 1.0), d_hits=None, d_shadow_hits=None,
+                      d_counts=None, stream=None):
+        """mr_render_direct: eye rays -> trace -> shadow rays -> trace -> Phong shade -> pixel means in one launch.
+        bands = (rows per band, rank, world) selects one rank's interleaved bands instead of the rows [y0,y1)."""
+        fd = FrameDesc()
+        fd.camera = cam
+        fd.W, fd.H, fd.y0, fd.y1 = W, H, y0, H if y1 is None else y1
+        fd.band_rows, fd.band_rank, fd.band_world = bands if bands is not None else (1, 0, 1)
+        fd.spp, fd.jitter, fd.seed, fd.tiled, fd.flags = spp, 1 if jitter else 0, seed, 1 if tiled else 0, flags
+        fd.light.position[:] = light_pos
+        fd.light.color[:] = color
+        fd.light.wattage = wattage
+        fd.diffuse[:] = diffuse
+        _check(self.L.mr_render_direct(self.h, C.byref(fd), d_rgb.data_ptr(),
+                                       d_hits.data_ptr() if d_hits is not None else None,
+                                       d_shadow_hits.data_ptr() if d_shadow_hits is not None else None,
+                                       d_counts.data_ptr() if d_counts is not None else None, _stream_ptr(stream)))
 
     def final_gather(self, global_map, caustic_map, d_rays, d_hits, n, d_scratch, d_rgb, max_dist=1e10, nphotons=500,
                      spp=1, stream=None):

@@ -112,6 +112,50 @@ def gather_framebuffer(local_rgb, H, W, band, rank, world, group=None, dst=0):
 
 
 # ------------------------------------------------------------------------------------------------ renderer
+class FusedFrame:
+    """One rank's share of a direct-light frame rendered by mr_render_direct: a single launch per step, no ray buffers.
+    Resident: the float framebuffer shard (12 B per pixel) and, when `keep_hits`, the two hit-record buffers
+    (16 + 16 B per sample) that parity tests compare with the batched pipeline's."""
+
+    def __init__(self, scene, desc, W, H, spp=1, band=None, rank=0, world=1, jitter=None, seed=168, flags=0, rgb=None,
+                 tiled=None, keep_hits=False, any_shadow=False):
+        if isinstance(desc, str):
+            desc = scenes.SCENES[desc]
+        self.scene, self.desc, self.W, self.H, self.spp = scene, desc, W, H, spp
+        self.jitter = (spp > 1) if jitter is None else jitter
+        self.seed = seed
+        self.flags = flags | (binding.MR_TRACE_ANY if any_shadow else 0)
+        self.device = torch.device("cuda", scene.device)
+        self.bands = (band, rank, world) if world > 1 else None
+        self.n_rows = sum(y1 - y0 for y0, y1 in band_rows(H, band, rank, world)) if world > 1 else H
+        self.n_pixels = self.n_rows * W
+        self.n = self.n_pixels * spp
+        self.tiled = (spp < 64) if tiled is None else bool(tiled)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.d_rgb = torch.zeros((max(self.n_pixels, 1), 3), **f32) if rgb is None else rgb
+        self.d_hits = torch.empty((max(self.n, 1), 4), **f32) if keep_hits else None
+        self.d_shadow_hits = torch.empty((max(self.n, 1), 4), **f32) if keep_hits else None
+        self.d_counts = torch.zeros(2, dtype=torch.int64, device=self.device)
+        self.cam = binding.make_camera(desc["eye"], desc["lookat"], desc["up"], desc["fov"])
+
+    def bytes_resident(self):
+        own = [self.d_rgb, self.d_counts] + [t for t in (self.d_hits, self.d_shadow_hits) if t is not None]
+        return sum(t.numel() * t.element_size() for t in own)
+
+    def step(self, stream=None):
+        if self.n == 0:
+            return
+        self.scene.render_direct(self.cam, self.W, self.H, self.d_rgb, self.desc["light"], self.desc["wattage"],
+                                 bands=self.bands, spp=self.spp, jitter=self.jitter, seed=self.seed, tiled=self.tiled,
+                                 flags=self.flags, d_hits=self.d_hits, d_shadow_hits=self.d_shadow_hits,
+                                 d_counts=self.d_counts, stream=stream)
+
+    def ray_counts(self, steps=1):
+        """(primary, shadow) rays per step, from the device counters accumulated over `steps` steps -- synchronises."""
+        c = self.d_counts.cpu().numpy()
+        return int(c[0]) // max(steps, 1), int(c[1]) // max(steps, 1)
+
+
 class FrameRenderer:
     """All device buffers of one rank's share of a frame, resident for the lifetime of the object."""
 

@@ -218,6 +218,32 @@ typedef struct mr_light {                             /* PointLight.h:8-59 */
 mr_status mr_shade_direct(mr_scene *scene, const mr_ray *d_rays, const mr_hit *d_hits, uint64_t n,
                           const mr_hit *d_shadow_hits, const uint32_t *d_shadow_src, const uint64_t *d_shadow_count,
                           const mr_light *light, const float diffuse[3], uint32_t spp, float *d_rgb, void *stream);
+/* ---- the whole direct-light frame step in ONE launch ------------------------------------------------------------
+ * Scene::raytraceImage's loop for a window of rows (Scene.cpp:112-141): for every sample Camera::eyeRay ->
+ * Scene::trace -> the shadow ray of Phong::shade (Phong.cpp:80-97) -> Scene::trace -> Phong::shade -> the pixel's
+ * mean.  The same rays, hit records and pixels, bit for bit, as
+ *   mr_gen_eye_rays[_tiled] -> mr_trace -> mr_gen_shadow_rays -> mr_trace_indirect -> mr_shade_direct [-> mr_untile_pixels]
+ * without any ray buffer: rays live in registers, the shadow ray is built from the hit the lane still holds.
+ * Rows of the window: [y0,y1) when band_world == 1; otherwise the interleaved bands of one rank of a multi-GPU frame
+ * (bands of band_rows rows dealt round-robin: rank r owns bands r, r + band_world, ...; y0/y1 ignored).
+ * spp: a power of two <= 64 (other counts: use the batched calls).  tiled: sample order of mr_gen_eye_rays_tiled over
+ * the window's rows (sample k of d_hits / d_shadow_hits follows that order); d_rgb is always in image order.
+ * flags: MR_MATH_PRODUCT, MR_TRACE_INCOHERENT (both rays), MR_TRACE_ANY (shadow ray only). */
+typedef struct mr_frame_desc {
+    mr_camera camera;
+    uint32_t  W, H, y0, y1;
+    uint32_t  band_rows, band_rank, band_world;   /* band_world <= 1: the contiguous window [y0,y1) */
+    uint32_t  spp, jitter, seed, tiled, flags;
+    mr_light  light;
+    float     diffuse[3];
+    uint32_t  reserved[4];
+} mr_frame_desc;
+/* d_rgb: rows*W*3 floats (window rows in band order).  Optional device outputs (NULL to skip): d_hits / d_shadow_hits,
+ * rows*W*spp records each -- the shadow record of a sample whose primary ray missed is {t = 0, prim = MR_MISS};
+ * d_counts[2]: += primary rays, += shadow rays traced (not zeroed by the call). */
+mr_status mr_render_direct(mr_scene *scene, const mr_frame_desc *frame, float *d_rgb, mr_hit *d_hits, mr_hit *d_shadow_hits,
+                           uint64_t *d_counts, void *stream);
+
 /* ---- specular materials and secondary rays ("next" row: Scene::traceScene's recursion, Scene.cpp:302-336) -------- */
 typedef struct mr_material {                          /* Phong(kd, ks, kt, shininess, refractIndex), Phong.h:10-14 */
     float diffuse[3], specular[3], transmission[3], shininess, refract_index;

@@ -27,10 +27,20 @@ def test_bench_prints_one_contract_line():
     assert j["value"] > 0 and j["ms_per_step"] > 0
     assert "workload" in j["config"] and "model" not in j["config"]
     rf = j["roofline"]
-    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    # the bound is the resource that limits the kernel (VALU issue, from SQ counters), so the fraction is a fraction
+    assert rf["bound"] == "valu_issue" and rf["unit"] == "Ginstr/s" and rf["peak"] == 1228.8
+    assert rf["pmc_source"], rf
+    assert rf["frac"] is not None and 0.0 < rf["frac"] <= 1.0, rf
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
+    assert 0.0 < rf["lane_utilisation"] <= 1.0
+    hb = rf["hbm"]
+    assert hb["peak_GBps"] == 8000.0 and hb["nominal_algorithmic_GBps"] > 0 and "NOT a bound" in hb["nominal_label"]
+    if rf["traffic"] is not None:
+        assert 0.0 < hb["hbm_measured_frac"] <= 1.0
     cb = j["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mrays/s" and cb["sample"]
+    assert cb["threads_used"] == cb["cores"] and cb["affinity_cores"] >= 1 and cb["host_cpus"] >= 1 and cb["runs"]
+    assert j["config"]["resident_bytes_per_gpu"] < 64 << 20        # no ray buffers: framebuffer + scene only
     # rays per step = primary + shadow of the frame actually traced
     assert j["config"]["rays_per_step"] >= 320 * 184 * 4
 

@@ -1,0 +1,134 @@
+"""mr_render_direct (the fused frame kernel, mr_frame.hip) against the batched pipeline it replaces:
+mr_gen_eye_rays[_tiled] -> mr_trace -> mr_gen_shadow_rays -> mr_trace_indirect -> mr_shade_direct [-> untile].
+Both are built from the same device functions, so everything must agree bit for bit: primary hit records, the
+shadow ray's hit record of every sample, the ray counts and the float framebuffer.  The batched pipeline itself is
+compared with the oracle in tests/test_frame.py (test_frame_pipeline_matches_oracle)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import product_scene
+from miro_amd import binding
+from miro_amd import frame as mframe
+from miro_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(t):
+    return t.detach().cpu().contiguous().view(torch.int32).numpy()
+
+
+def _compare(miro, sc, name, W, H, spp, tiled, flags=0, any_shadow=False, jitter=None):
+    ref = mframe.FrameRenderer(sc, name, W, H, spp=spp, jitter=jitter, flags=flags, tiled=tiled)
+    ref.generate()
+    ref.step(any_hit=any_shadow)
+    fu = mframe.FusedFrame(sc, name, W, H, spp=spp, jitter=jitter, flags=flags, tiled=tiled, keep_hits=True,
+                           any_shadow=any_shadow)
+    assert fu.tiled == ref.tiled or spp >= 64 or spp & (spp - 1)
+    fu.step()
+    torch.cuda.synchronize()
+    n_p, n_s = ref.ray_counts()
+    assert fu.ray_counts() == (n_p, n_s)
+    # primary hit records: same sample order (image order, or the tiled order of the window)
+    assert np.array_equal(_bits(fu.d_hits), _bits(ref.d_hits))
+    # shadow records: the batched pipeline compacts them; d_src maps a shadow ray to its sample
+    src = ref.d_src[:n_s].to(torch.int64)
+    got = fu.d_shadow_hits[src]
+    if any_shadow:       # any-hit: which occluder is reported depends on nothing but the ray, still identical
+        assert np.array_equal(_bits(got), _bits(ref.d_shadow_hits[:n_s]))
+    else:
+        assert np.array_equal(_bits(got), _bits(ref.d_shadow_hits[:n_s]))
+    no_ray = torch.ones(ref.n, dtype=torch.bool, device=src.device)
+    no_ray[src] = False
+    rest = fu.d_shadow_hits[no_ray]
+    assert (rest[:, 0] == 0).all() and (rest[:, 1].view(torch.int32) == -1).all()
+    # the picture, in image order
+    assert np.array_equal(_bits(fu.d_rgb), _bits(ref.d_rgb))
+    return fu, ref
+
+
+@pytest.mark.parametrize("name,W,H,spp,tiled", [
+    ("teapot", 128, 96, 1, False), ("teapot", 128, 96, 1, True), ("teapot", 97, 61, 4, True), ("bunny", 80, 45, 16, True),
+    ("bunny", 80, 45, 16, False), ("sponza", 64, 36, 64, False), ("sponza", 150, 101, 2, True), ("cornell", 33, 31, 32, True),
+    ("sponza", 31, 17, 8, False)])
+def test_fused_frame_equals_the_batched_pipeline(miro, name, W, H, spp, tiled):
+    sc = product_scene(miro, name)
+    _compare(miro, sc, name, W, H, spp, tiled)
+
+
+@pytest.mark.parametrize("flags", ["product", "incoherent", "product+incoherent", "any"])
+def test_fused_frame_modes(miro, flags):
+    sc = product_scene(miro, "sponza")
+    fl = 0
+    if "product" in flags:
+        fl |= binding.MR_MATH_PRODUCT
+    if "incoherent" in flags:
+        fl |= binding.MR_TRACE_INCOHERENT
+    _compare(miro, sc, "sponza", 120, 67, 4, True, flags=fl, any_shadow=flags == "any")
+
+
+def test_fused_frame_with_spheres_and_planes(miro):
+    sc = product_scene(miro, "spiral")
+    _compare(miro, sc, "spiral", 96, 64, 4, True)
+    _compare(miro, sc, "spiral", 96, 64, 1, False)
+
+
+@pytest.mark.parametrize("world,band", [(2, 6), (4, 6), (8, 5), (3, 8)])
+def test_fused_frame_of_one_ranks_bands(miro, world, band):
+    """The interleaved bands of each rank (band_rows rule of frame.band_rows), rendered by one launch per rank, put
+    together give the unsharded frame byte for byte -- tiles that straddle two bands included."""
+    name, W, H, spp = "sponza", 96, 54, 4
+    sc = product_scene(miro, name)
+    whole = mframe.FusedFrame(sc, name, W, H, spp=spp)
+    whole.step()
+    full = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    tot = [0, 0]
+    for r in range(world):
+        fu = mframe.FusedFrame(sc, name, W, H, spp=spp, band=band, rank=r, world=world)
+        fu.step()
+        rows = torch.from_numpy(mframe.rows_of(mframe.band_rows(H, band, r, world))).to("cuda")
+        assert fu.n_rows == len(rows)
+        if len(rows):
+            full[rows] = fu.d_rgb.view(len(rows), W, 3)
+        c = fu.ray_counts()
+        tot[0] += c[0]
+        tot[1] += c[1]
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits(full.view(-1, 3)), _bits(whole.d_rgb))
+    assert tuple(tot) == whole.ray_counts()
+
+
+def test_fused_frame_rejects_what_it_cannot_do(miro):
+    sc = product_scene(miro, "teapot")
+    rgb = torch.zeros((16 * 16, 3), dtype=torch.float32, device="cuda")
+    cam = binding.make_camera(*[scenes.SCENES["teapot"][k] for k in ("eye", "lookat", "up", "fov")])
+    with pytest.raises(miro.MiroError):
+        sc.render_direct(cam, 16, 16, rgb, (0, 1, 0), 100.0, spp=3)
+    with pytest.raises(miro.MiroError):
+        sc.render_direct(cam, 16, 16, rgb, (0, 1, 0), 100.0, spp=128)
+    with pytest.raises(miro.MiroError):
+        sc.render_direct(cam, 16, 16, rgb, (0, 1, 0), 100.0, y0=8, y1=20)
+    with pytest.raises(miro.MiroError):
+        sc.render_direct(cam, 16, 16, rgb, (0, 1, 0), 100.0, flags=binding.MR_COUNT_STATS)
+
+
+def test_fused_frame_full_size_properties(miro):
+    """BASELINE config 4 at full size (1920x1080, 64 spp is 132.7 M samples: 16 spp here keeps the hit buffers at 1 GB):
+    size-independent checks -- idempotence (two steps, same bytes), ray-count conservation (closed scene: one shadow ray
+    per primary ray), and equality with the batched pipeline's picture."""
+    name, W, H, spp = "sponza", 1920, 1080, 16
+    sc = product_scene(miro, name)
+    fu = mframe.FusedFrame(sc, name, W, H, spp=spp)
+    fu.step()
+    a = fu.d_rgb.clone()
+    fu.step()
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int32), fu.d_rgb.view(torch.int32))
+    n_p, n_s = fu.ray_counts(steps=2)
+    assert n_p == W * H * spp and n_s == n_p
+    ref = mframe.FrameRenderer(sc, name, W, H, spp=spp, tiled=True)
+    ref.generate()
+    ref.step()
+    torch.cuda.synchronize()
+    assert torch.equal(ref.d_rgb.view(torch.int32), fu.d_rgb.view(torch.int32))
