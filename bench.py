@@ -386,7 +386,9 @@ def main():
                        "flags": {"product": a.product, "incoherent": a.incoherent, "any_shadow": a.any_shadow, "tiled": tiled}}
                 try:
                     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-                    json.dump(rec, open(os.path.join(ROOT, "gpurun_out", "r02_bench_pmc.json"), "w"), indent=1)
+                    default_frame = (a.scene, W, H, spp) == ("sponza", 1920, 1080, 64) and not (a.product or a.incoherent or a.any_shadow)
+                    name = "r02_bench_pmc.json" if default_frame else "r02_bench_pmc_%s_%dx%d_%dspp.json" % (a.scene, W, H, spp)
+                    json.dump(rec, open(os.path.join(ROOT, "gpurun_out", name), "w"), indent=1)
                 except Exception:
                     pass
         if pmc is None:
