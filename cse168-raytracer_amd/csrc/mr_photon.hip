@@ -13,9 +13,16 @@
 // seeing those photons, applied lazily, so a superset of nodes is visited and the same k photons survive.
 //
 // Kept from the reference: nodes with index >= stored/2-1 do not descend; the normalising radius stays
-// max_dist^2 unless more than k candidates were seen; strict comparisons.  Not kept: the order in which powers
-// are summed (float rounding, ~1e-6 relative) and the reference's first-overflow replacement, which may trade one
-// boundary photon.
+// max_dist^2 unless more than k candidates were seen; strict comparisons; and the FIRST-OVERFLOW REPLACEMENT
+// (PhotonMap.cpp:195-240): when candidate k+1 arrives the reference heapifies the k it holds and replaces the heap
+// root -- the farthest of the first k, m* -- by the newcomer even when the newcomer is farther still, and only from
+// then on does the radius follow the heap root.  m* therefore never takes part in the result: what the reference
+// returns is the k nearest of (all candidates minus m*).  Which photon m* is depends on the reference's visiting
+// order (near side first, a node after its subtrees), so a first pass walks exactly that order, one query per lane,
+// until k+1 candidates have been seen (first_overflow below); the wave-cooperative search then skips m*.
+// found and the radius are the reference's on every query.  Not kept: the order in which the powers are summed
+// (float rounding, ~1e-6 relative), and which of two photons at exactly the same squared distance is dropped when they
+// tie for m* or at the k-th place (the reference's heap layout decides; distances, found and radius are unaffected).
 #include <hip/hip_runtime.h>
 
 #include "mr_internal.h"
@@ -38,6 +45,14 @@ struct WaveLds {
     int slot[64];            // children of one block, indexed by visiting-order key
     float slot_lb[64];
 };
+
+// a cross-lane hand-off through wave-private LDS: release + acquire at wavefront scope and a wave barrier, so that neither
+// the compiler nor the memory model may move LDS accesses across it (no instruction is emitted beyond a waitcnt)
+__device__ __forceinline__ void lds_handoff() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // k-th smallest (1-based rank `k`) of d2[0..count): returns its bit pattern and how many entries equal to it belong
 // to the k smallest.  Non-negative floats order like their bit patterns.
@@ -110,6 +125,58 @@ __device__ __forceinline__ float compress(WaveLds &w, int &count, int k, int lan
     return __uint_as_float(kth);
 }
 
+// locate_photons (PhotonMap.cpp:152-243) in the reference's own order while np->dist2[0] is still max_dist^2, i.e. up
+// to the first overflow: near child first, the far child if the splitting plane is inside max_dist, the node itself
+// after both.  No stack: the path is implicit in the heap index, and whether a child was the near one is kept as one bit
+// per level.  Returns the index of the farthest of the first k candidates (earliest among equals) once candidate k+1
+// has been seen; 0 when the whole (reachable) tree holds at most k candidates.
+__device__ __forceinline__ int first_overflow(const PhotonMapDev &pm, float qx, float qy, float qz, float nx, float ny, float nz,
+                                              float md2, int k) {
+    if (pm.n < 1) return 0;
+    int i = 1, cnt = 0, best_i = 0;
+    float best_d2 = -1.0f;
+    unsigned near_right = 0;              // bit d: at the ancestor of depth d the near child was the right one
+    bool descend = true;
+    while (true) {
+        if (descend && i < pm.half) {                                       // :160-172, going down
+            const float4 A = pm.posplane[i];
+            const int plane = __float_as_int(A.w);
+            const float side = (plane == 0 ? qx : (plane == 1 ? qy : qz)) - (plane == 0 ? A.x : (plane == 1 ? A.y : A.z));
+            const int d = 31 - __clz(i);
+            const unsigned right = side > 0.0f ? 1u : 0u;
+            near_right = (near_right & ~(1u << d)) | (right << d);
+            i = 2 * i + (int)right;
+            continue;
+        }
+        // the photon at node i (:177-186)
+        {
+            const float4 A = pm.posplane[i], D = pm.dir[i];
+            float dd = A.x - qx;
+            float d2 = dd * dd;
+            dd = A.y - qy; d2 += dd * dd;
+            dd = A.z - qz; d2 += dd * dd;
+            const float facing = (D.x * nx + D.y * ny) + D.z * nz;
+            if (d2 < md2 && facing < 0.0f) {
+                if (++cnt > k) return best_i;                               // candidate k+1: the heap root goes (:222-238)
+                if (d2 > best_d2) { best_d2 = d2; best_i = i; }
+            }
+        }
+        // back up: a near child hands over to its far sibling (if the plane is inside the radius), a far child to the parent
+        if (i == 1) return 0;
+        const int parent = i >> 1;
+        const int d = 31 - __clz(parent);
+        const bool was_near = (unsigned)(i & 1) == ((near_right >> d) & 1u);
+        descend = false;
+        if (was_near) {
+            const float4 A = pm.posplane[parent];
+            const int plane = __float_as_int(A.w);
+            const float side = (plane == 0 ? qx : (plane == 1 ? qy : qz)) - (plane == 0 ? A.x : (plane == 1 ? A.y : A.z));
+            if (side * side < md2) { i ^= 1; descend = true; continue; }
+        }
+        i = parent;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, const float *qpos, const float *qnrm,
                                                             unsigned long long nq, float max_dist, int k, float *irrad,
                                                             int *found_out, float *r2_out) {
@@ -123,7 +190,23 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
     const int off_in_level = lane + 1 - (1 << lv);
     const bool node_lane = lane < 63;
 
-    for (unsigned long long q = wave_id; q < nq; q += n_waves) {
+    const float md2 = max_dist * max_dist;
+    // a wave takes 64 consecutive queries at a time: first every lane finds its own query's m* (first_overflow), then
+    // the wave searches the 64 queries one after the other
+    for (unsigned long long base = wave_id * 64ull; base < nq; base += n_waves * 64ull) {
+      int my_mstar = 0;
+      {
+          const unsigned long long qa = base + (unsigned)lane;
+          if (qa < nq) {
+              const float ax = qnrm[3 * qa];
+              if (ax == ax)
+                  my_mstar = first_overflow(pm, qpos[3 * qa], qpos[3 * qa + 1], qpos[3 * qa + 2], ax, qnrm[3 * qa + 1], qnrm[3 * qa + 2], md2, k);
+          }
+      }
+      const int n_here = nq - base < 64ull ? (int)(nq - base) : 64;
+      for (int t = 0; t < n_here; t++) {
+        const unsigned long long q = base + (unsigned)t;
+        const int mstar = __shfl(my_mstar, t, 64);            // 0: this query never overflows
         const float qx = qpos[3 * q], qy = qpos[3 * q + 1], qz = qpos[3 * q + 2];
         const float nx = qnrm[3 * q], ny = qnrm[3 * q + 1], nz = qnrm[3 * q + 2];
         if (nx != nx) {                                       // NaN normal = "no query here" (mr_final_gather: miss / non-diffuse hit)
@@ -134,13 +217,15 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
             }
             continue;
         }
-        const float md2 = max_dist * max_dist;
         float r2 = md2;                                       // np.dist2[0] (PhotonMap.cpp:99)
         int count = 0;
         bool evicted = false;
         int sp = 0;
         if (pm.n >= 1) { if (lane == 0) { w.stack[0] = 1; w.lb[0] = 0.0f; } sp = 1; }
 
+        // LDS words written by one lane and read by another lane of the same wave: the hardware keeps a wave's LDS
+        // operations in order, the compiler is kept from moving them across each hand-off by lds_handoff()
+        lds_handoff();
         while (sp > 0) {
             sp--;
             const int b = w.stack[sp];                        // same address in every lane: LDS broadcast
@@ -190,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
             dd = A.y - qy; d2 += dd * dd;
             dd = A.z - qz; d2 += dd * dd;
             const float facing = (D.x * nx + D.y * ny) + D.z * nz;
-            const bool cand = reach && d2 < r2 && facing < 0.0f;
+            const bool cand = reach && d2 < r2 && facing < 0.0f && j != mstar;      // m* never takes part (see the header)
             const unsigned long long mc = __ballot(cand);
             if (cand) {
                 const int pos = count + __popcll(mc & ((1ull << lane) - 1ull));
@@ -200,13 +285,16 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
             // children of the level-5 nodes become block roots, pushed so that they pop in the reference's order:
             // key = far-step bits of the whole path (6 bits, unique per child); slot[key] is filled by its owner,
             // then lane `key` moves it to the stack behind all larger keys
+            lds_handoff();                                    // candidate append above / slot reuse below
             w.slot[lane] = 0;
+            lds_handoff();
             const bool can_push = valid && lv == 5 && reach && desc;
             const int near_child = d1 > 0.0f ? 2 * j + 1 : 2 * j;
             const int far_child = near_child ^ 1;
             const float dsq = d1 * d1;
             if (can_push && near_child <= pm.n) { w.slot[path << 1] = near_child; w.slot_lb[path << 1] = lb; }
             if (can_push && far_child <= pm.n && dsq < r2) { w.slot[(path << 1) | 1] = far_child; w.slot_lb[(path << 1) | 1] = fmaxf(lb, dsq); }
+            lds_handoff();                                    // slot[] filled by the level-5 lanes, read by lane `key`
             const int child = w.slot[lane];
             const float child_lb = w.slot_lb[lane];
             const unsigned long long mp = __ballot(child != 0);
@@ -216,13 +304,22 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
                 w.stack[pos] = child; w.lb[pos] = child_lb;
             }
             sp += __popcll(mp);
+            lds_handoff();                                    // stack[] / lb[] entries are popped by every lane next round
             if (count > kTighten && count > k) {              // keep the k nearest so far; the k-th is the new radius
                 r2 = compress(w, count, k, lane);
                 evicted = true;
             }
         }
         if (count > k) { r2 = compress(w, count, k, lane); evicted = true; }
+        else if (mstar != 0) {
+            // exactly k candidates besides m*: the reference's heap holds them all and its root is the farthest
+            float mx = 0.0f;
+            for (int i = lane; i < count; i += 64) mx = fmaxf(mx, w.d2[i]);
+            for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+            r2 = mx; evicted = true;
+        }
         const float r2_final = evicted ? r2 : md2;            // dist2[0] only moves once the heap overflows (:240)
+        lds_handoff();
         float sr = 0.f, sg = 0.f, sb = 0.f;
         for (int i = lane; i < count; i += 64) {
             const float4 P = pm.power[w.idx[i]];
@@ -237,6 +334,7 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
             if (found_out) found_out[q] = count;
             if (r2_out) r2_out[q] = r2_final;
         }
+      }
     }
 }
 

@@ -89,7 +89,8 @@ def test_oracle_search_equals_brute_force(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,k,md", [(200000, 500, 1e10), (200000, 50, 1e10), (30000, 500, 0.6), (300, 500, 1e10), (2, 10, 1e10)])
+@pytest.mark.parametrize("n,k,md", [(200000, 500, 1e10), (200000, 50, 1e10), (30000, 500, 0.6), (300, 500, 1e10), (2, 10, 1e10),
+                                    (20000, 4, 1e10), (20000, 9, 0.8), (5000, 1, 1e10), (700, 300, 1e10), (64, 63, 1e10)])
 def test_irradiance_estimate_matches_oracle(oracle, miro, n, k, md):
     import torch
     a, b, (v, vi) = make_maps(oracle, miro, n, scene="sponza", host_only=False)
@@ -103,15 +104,26 @@ def test_irradiance_estimate_matches_oracle(oracle, miro, n, k, md):
     b.irradiance_estimate(dq, dn, len(qpos), out, max_dist=md, nphotons=k, d_found=df, d_r2=dr)
     torch.cuda.synchronize()
     got = out.cpu().numpy()
+    # found and the radius np.dist2[0] are the reference's on EVERY query, first-overflow replacement included
+    # (PhotonMap.cpp:195-240: the k+1-th candidate replaces the heap root even when it is farther)
     assert np.array_equal(df.cpu().numpy(), found)
-    # radius: identical except where the reference's first-overflow replacement traded one boundary photon
-    same_r = dr.cpu().numpy().view(np.uint32) == r2.view(np.uint32)
-    assert same_r.mean() > 0.995
+    assert np.array_equal(dr.cpu().numpy().view(np.uint32), r2.view(np.uint32))
     scale = np.abs(want).max()
     err = np.abs(got - want).max(axis=1)
-    assert (err[same_r] <= 1e-5 * scale).all()
-    assert (err <= 1e-2 * scale).all()
+    assert (err <= 1e-5 * scale).all()          # summation order only
     assert want.max() > 0 or n < 10
+
+
+def test_first_overflow_replacement_changes_results(oracle, miro):
+    """The quirk the device reproduces is live in these parameter sets: with small k the reference's answer differs from
+    the true k nearest candidates on a sizeable share of the queries (so the equality above is not vacuous)."""
+    from miro_amd import scenes as sc
+    a, _, (v, vi) = make_maps(oracle, miro, 20000, scene="sponza", host_only=True)
+    _, qpos, qdir = sc.synthetic_photons(v, vi, 3000, seed=99)
+    ref = a.irradiance_estimate(qpos, -qdir, max_dist=1e10, nphotons=4)
+    true = a.irradiance_estimate(qpos, -qdir, max_dist=1e10, nphotons=4, brute=True)
+    differ = ref[2].view(np.uint32) != true[2].view(np.uint32)
+    assert 0.01 < differ.mean() < 0.9
 
 
 @pytest.mark.gpu
@@ -151,8 +163,7 @@ def test_final_gather_frame_matches_oracle(oracle, miro):
     err = np.abs(added - want).max(axis=1)
     # `added` is a difference of two fp32 pictures: its own rounding is ~1e-7 of the direct term
     tol = 1e-5 * scale + 4e-7 * float(direct.max())
-    assert (err <= tol).mean() > 0.995          # a boundary photon traded by the first-overflow quirk (see above)
-    assert (err <= 1e-2 * scale + tol).all()
+    assert (err <= tol).all()
     # pixels whose samples all missed receive nothing
     all_miss = ~hit.reshape(H * W, spp).any(axis=1)
     assert all_miss.any() and (added[all_miss] == 0).all()
