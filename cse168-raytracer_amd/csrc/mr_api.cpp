@@ -687,6 +687,22 @@ mr_status mr_gen_secondary_rays(mr_scene *s, const mr_ray *d_rays, const mr_hit 
                                  reinterpret_cast<unsigned long long *>(d_count), static_cast<hipStream_t>(stream));
 }
 
+mr_status mr_gen_path_rays(mr_scene *s, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
+                           const uint32_t *d_pixels, const uint32_t *d_ids, uint64_t n, uint32_t spp, uint32_t seed,
+                           uint32_t bounce, uint32_t kinds, mr_ray *d_out_rays, float *d_out_weights, uint32_t *d_out_pixels,
+                           uint32_t *d_out_ids, uint64_t *d_count, void *stream) {
+    mr_status st = require_device(s);
+    if (st != MR_OK) return st;
+    if (!d_rays || !d_hits || !d_out_rays || !d_out_weights || !d_out_pixels || !d_count) return fail(MR_ERR_INVALID, "NULL argument");
+    if (spp == 0) return fail(MR_ERR_INVALID, "spp is 0");
+    if (n / spp > 0xFFFFFFFFull || n > 0xFFFFFFFFull) return fail(MR_ERR_INVALID, "too many rays for 32-bit ray ids");
+    if (kinds == 0 || (kinds & ~7u)) return fail(MR_ERR_INVALID, "kinds must be a combination of MR_PATH_MIRROR | MR_PATH_REFRACT | MR_PATH_DIFFUSE");
+    MR_HIP_CHECK(hipSetDevice(s->device));
+    return launch_path_rays(s->dev, d_rays, d_hits, d_weights, d_pixels, d_ids, n, spp, seed, bounce, kinds, d_out_rays,
+                            d_out_weights, d_out_pixels, d_out_ids, reinterpret_cast<unsigned long long *>(d_count),
+                            static_cast<hipStream_t>(stream));
+}
+
 mr_status mr_tonemap(mr_scene *s, const float *d_rgb, uint64_t n_values, uint8_t *d_out, void *stream) {
     if (!s || !d_rgb || !d_out) return fail(MR_ERR_INVALID, "NULL argument");
     MR_HIP_CHECK(hipSetDevice(s->device));

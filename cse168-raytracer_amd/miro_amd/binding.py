@@ -24,6 +24,8 @@ MR_TRACE_PERSISTENT = 1 << 5
 MR_MATH_PRODUCT = 1 << 6
 MR_TRACE_INCOHERENT = 1 << 7
 
+MR_PATH_MIRROR, MR_PATH_REFRACT, MR_PATH_DIFFUSE = 1, 2, 4
+
 MR_OK, MR_ERR_INVALID, MR_ERR_IO, MR_ERR_NOMEM, MR_ERR_HIP, MR_ERR_STATE = 0, -1, -2, -3, -4, -5
 
 # every symbol include/miro_hip.h declares (tests check the library exports each one)
@@ -32,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "mr_scene_add_sphere", "mr_scene_add_plane",
     "mr_bvh_build", "mr_scene_get_info", "mr_scene_get_mesh", "mr_scene_export_tree",
     "mr_trace", "mr_host_alloc", "mr_host_free", "mr_trace_indirect", "mr_trace_get_stats", "mr_gen_eye_rays", "mr_gen_eye_rays_tiled", "mr_tile_pixel_map", "mr_untile_pixels", "mr_gen_shadow_rays", "mr_hit_attrs",
-    "mr_shade_direct", "mr_render_direct", "mr_tonemap",
+    "mr_shade_direct", "mr_render_direct", "mr_gen_path_rays", "mr_tonemap",
     "mr_scene_set_materials", "mr_shade_accumulate", "mr_gen_secondary_rays",
     "mr_photon_map_create", "mr_photon_map_destroy", "mr_photon_map_store", "mr_photon_map_scale",
     "mr_photon_map_balance", "mr_photon_map_count", "mr_photon_map_export", "mr_irradiance_estimate",
@@ -149,6 +151,7 @@ def load_library(path=None):
     L.mr_scene_set_materials.argtypes = [vp, C.POINTER(Material), C.c_uint32, u32p]
     L.mr_shade_accumulate.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, C.POINTER(Light), C.c_uint32, vp, vp]
     L.mr_gen_secondary_rays.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp, vp]
+    L.mr_gen_path_rays.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp]
     L.mr_final_gather.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_float, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.mr_photon_map_create.argtypes = [C.c_int32, C.c_uint32, C.POINTER(vp)]
     L.mr_photon_map_destroy.argtypes = [vp]
@@ -382,6 +385,15 @@ class Scene:
         _check(self.L.mr_shade_direct(self.h, d_rays.data_ptr(), d_hits.data_ptr(), n, d_shadow_hits.data_ptr(),
                                       d_shadow_src.data_ptr(), d_shadow_count.data_ptr(), C.byref(lt), _f32p(df), spp,
                                       d_rgb.data_ptr(), _stream_ptr(stream)))
+
+    def gen_path_rays(self, d_rays, d_hits, d_weights, d_pixels, d_ids, n, d_out_rays, d_out_weights, d_out_pixels, d_out_ids,
+                      d_count, spp=1, seed=168, bounce=0, kinds=MR_PATH_MIRROR | MR_PATH_REFRACT | MR_PATH_DIFFUSE, stream=None):
+        """mr_gen_path_rays: the PATH_TRACING generators (Ray.h:124-158,235-239): up to 4 children per hit"""
+        def ptr(t):
+            return t.data_ptr() if t is not None else None
+        _check(self.L.mr_gen_path_rays(self.h, d_rays.data_ptr(), d_hits.data_ptr(), ptr(d_weights), ptr(d_pixels), ptr(d_ids),
+                                       n, spp, seed, bounce, kinds, d_out_rays.data_ptr(), d_out_weights.data_ptr(),
+                                       d_out_pixels.data_ptr(), ptr(d_out_ids), d_count.data_ptr(), _stream_ptr(stream)))
 
     def render_direct(self, cam, W, H, d_rgb, light_pos, wattage, y0=0, y1=None, bands=None, spp=1, jitter=False, seed=168,
                       tiled=False, flags=0, color=(1.0, 1.0, 1.0), diffuse=(1.0, 1.0, 1.0), d_hits=None, d_shadow_hits=None,

@@ -268,6 +268,19 @@ mr_status mr_gen_secondary_rays(mr_scene *scene, const mr_ray *d_rays, const mr_
                                 const uint32_t *d_pixels, uint64_t n, uint32_t spp, mr_ray *d_out_rays, float *d_out_weights,
                                 uint32_t *d_out_pixels, uint64_t *d_count, void *stream);
 
+/* The PATH_TRACING build of those generators (Ray.h:149-158,235-239) plus Ray::random (Ray.h:124-140): every child is
+ * drawn from a lobe (alignHemisphereToVector, Utility.h:34-50) around the mirror / refracted direction with
+ * phi = acos(pow(u1, 1/(1+shininess))), or -- the diffuse bounce -- around the normal with phi = asin(sqrt(u1));
+ * theta = 2 pi u2.  u1, u2 replace the reference's rand() by the counter-based generator of the eye-ray jitter, keyed by
+ * (seed, ray id, bounce, child kind).  kinds selects the children: MR_PATH_MIRROR | MR_PATH_REFRACT (Scene.cpp:302-336)
+ * | MR_PATH_DIFFUSE (an extension: traceScene at HEAD never calls Ray::random); up to four children per ray (room for
+ * 4n).  d_ids (NULL = ray index) are stable ray ids, d_out_ids (may be NULL) receives the children's. */
+enum { MR_PATH_MIRROR = 1u, MR_PATH_REFRACT = 2u, MR_PATH_DIFFUSE = 4u };
+mr_status mr_gen_path_rays(mr_scene *scene, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
+                           const uint32_t *d_pixels, const uint32_t *d_ids, uint64_t n, uint32_t spp, uint32_t seed,
+                           uint32_t bounce, uint32_t kinds, mr_ray *d_out_rays, float *d_out_weights, uint32_t *d_out_pixels,
+                           uint32_t *d_out_ids, uint64_t *d_count, void *stream);
+
 /* sigmoid(6v-3) tone map + 8-bit quantisation (Scene.cpp:87-91,177-202; Image.cpp:44-50) */
 mr_status mr_tonemap(mr_scene *scene, const float *d_rgb, uint64_t n_values, uint8_t *d_out, void *stream);
 

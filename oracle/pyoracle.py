@@ -72,6 +72,10 @@ def lib():
         L.orc_tonemap.argtypes = [f32p, C.c_uint64, vp]
         L.orc_trace_scene.argtypes = [vp, f32p, u32p, vp, C.c_uint64, f32p, f32p, C.c_float, C.c_int, f32p]
         L.orc_trace_scene.restype = C.c_uint64
+        L.orc_path_rays.argtypes = [vp, f32p, u32p, vp, vp, f32p, u32p, u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.c_uint32, vp, f32p, u32p, u32p, u32p]
+        L.orc_path_rays.restype = C.c_uint64
+        L.orc_miro_math.argtypes = [f32p, f32p, C.c_uint64, f32p]
         L.orc_pmap_new.argtypes = [C.c_int]
         L.orc_pmap_new.restype = vp
         L.orc_pmap_free.argtypes = [vp]
@@ -241,6 +245,26 @@ class Scene:
                                        wattage, depth, _f32p(rgb))
         return rgb, calls
 
+    def path_rays(self, materials, prim_mat, rays, hits, weights=None, pixels=None, ids=None, spp=1, seed=168, bounce=0, kinds=7):
+        """The PATH_TRACING generators (miro_oracle_path.c): children of every hit in ray order.
+        Returns (rays, weights [m,3], pixels, ids, kinds)."""
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        m = np.ascontiguousarray(materials, dtype=np.float32).reshape(-1, 11)
+        pm = np.ascontiguousarray(prim_mat, dtype=np.uint32) if prim_mat is not None else None
+        n = len(rays)
+        w = np.ascontiguousarray(weights, dtype=np.float32) if weights is not None else None
+        px = np.ascontiguousarray(pixels, dtype=np.uint32) if pixels is not None else None
+        idv = np.ascontiguousarray(ids, dtype=np.uint32) if ids is not None else None
+        out = np.empty(4 * n, RAY_DTYPE)
+        ow = np.empty((4 * n, 3), np.float32)
+        op, oi, ok = (np.empty(4 * n, np.uint32) for _ in range(3))
+        cnt = self.L.orc_path_rays(self.h, _f32p(m), _u32p(pm) if pm is not None else None, rays.ctypes.data, hits.ctypes.data,
+                                   _f32p(w) if w is not None else None, _u32p(px) if px is not None else None,
+                                   _u32p(idv) if idv is not None else None, n, spp, seed, bounce, kinds, out.ctypes.data,
+                                   _f32p(ow), _u32p(op), _u32p(oi), _u32p(ok))
+        return out[:cnt].copy(), ow[:cnt].copy(), op[:cnt].copy(), oi[:cnt].copy(), ok[:cnt].copy()
+
     def hit_attrs(self, hits, rays=None):
         """HitInfo::P / ::N; `rays` is needed when the scene holds spheres or planes (P = o + t*d)."""
         hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
@@ -252,6 +276,15 @@ class Scene:
             rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
             self.L.orc_hit_attrs_rays(self.h, rays.ctypes.data, hits.ctypes.data, len(hits), _f32p(P), _f32p(N))
         return P, N
+
+
+def miro_math(x, y):
+    """include/miro_math.h on the host: columns sin, cos, asin01, acos01, pow01(x, y)"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    out = np.empty((len(x), 5), np.float32)
+    lib().orc_miro_math(_f32p(x), _f32p(y), len(x), _f32p(out))
+    return out
 
 
 class PhotonMap:
