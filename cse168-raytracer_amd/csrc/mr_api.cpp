@@ -604,6 +604,38 @@ mr_status mr_shade_direct(mr_scene *s, const mr_ray *d_rays, const mr_hit *d_hit
                         d_rgb, static_cast<hipStream_t>(stream));
 }
 
+mr_status mr_band_locate(uint32_t H, uint32_t band_rows, uint32_t world, uint32_t y, uint32_t *rank, uint32_t *local_row) {
+    if (band_rows == 0 || world == 0 || y >= H) return fail(MR_ERR_INVALID, "mr_band_locate: row %u of %u, bands of %u over %u ranks", y, H, band_rows, world);
+    const uint32_t band = y / band_rows;
+    if (rank) *rank = band % world;
+    if (local_row) *local_row = (band / world) * band_rows + y % band_rows;
+    return MR_OK;
+}
+
+mr_status mr_band_rows_of(uint32_t H, uint32_t band_rows, uint32_t rank, uint32_t world, uint32_t *rows) {
+    if (band_rows == 0 || world == 0 || rank >= world || !rows) return fail(MR_ERR_INVALID, "mr_band_rows_of: bad arguments");
+    uint32_t n = 0;
+    const uint32_t nb = (H + band_rows - 1) / band_rows;
+    for (uint32_t b = rank; b < nb; b += world) n += (b + 1) * band_rows <= H ? band_rows : H - b * band_rows;
+    *rows = n;
+    return MR_OK;
+}
+
+mr_status mr_deinterleave_bands(mr_scene *s, const float *d_recv, float *d_full, uint32_t W, uint32_t H, uint32_t band_rows,
+                                uint32_t world, uint32_t shard_rows, uint32_t floats_per_pixel, void *stream) {
+    mr_status st = require_device(s);
+    if (st != MR_OK) return st;
+    if (!d_recv || !d_full) return fail(MR_ERR_INVALID, "NULL argument");
+    if (band_rows == 0 || world == 0 || floats_per_pixel == 0) return fail(MR_ERR_INVALID, "mr_deinterleave_bands: bad band description");
+    for (uint32_t r = 0; r < world; r++) {
+        uint32_t rows = 0;
+        mr_band_rows_of(H, band_rows, r, world, &rows);
+        if (rows > shard_rows) return fail(MR_ERR_INVALID, "rank %u owns %u rows, the shards hold %u", r, rows, shard_rows);
+    }
+    MR_HIP_CHECK(hipSetDevice(s->device));
+    return launch_deinterleave(d_recv, d_full, W, H, band_rows, world, shard_rows, floats_per_pixel, static_cast<hipStream_t>(stream));
+}
+
 mr_status mr_render_direct(mr_scene *s, const mr_frame_desc *frame, float *d_rgb, mr_hit *d_hits, mr_hit *d_shadow_hits,
                            uint64_t *d_counts, void *stream) {
     mr_status st = require_device(s);

@@ -145,6 +145,8 @@ mr_status launch_gather_queries(const DeviceScene &ds, const mr_ray *d_rays, con
 mr_status launch_gather_accumulate(const float *d_irr_a, const float *d_irr_b, unsigned long long n, uint32_t spp,
                                    float *d_rgb, hipStream_t stream);
 mr_status launch_tonemap(const float *d_rgb, unsigned long long n_values, uint8_t *d_out, hipStream_t stream);
+mr_status launch_deinterleave(const float *d_recv, float *d_full, uint32_t W, uint32_t H, uint32_t band_rows, uint32_t world,
+                              uint32_t shard_rows, uint32_t fpp, hipStream_t stream);
 mr_status launch_untile(const float *d_slots, float *d_image, uint32_t W, uint32_t rows, uint32_t spp, uint32_t channels,
                         hipStream_t stream);
 

@@ -156,6 +156,19 @@ __global__ __launch_bounds__(kBlock) void untile_kernel(const float *slots, floa
     }
 }
 
+// image row y <- row `local` of rank `rank`'s shard (frame.band_rows rule): one thread per float
+__global__ __launch_bounds__(kBlock) void deinterleave_kernel(const float *recv, float *full, uint32_t W, uint32_t H, uint32_t band_rows,
+                                                              uint32_t world, uint32_t shard_rows, uint32_t fpp) {
+    const unsigned long long row_floats = (unsigned long long)W * fpp, n = row_floats * H;
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint32_t y = (uint32_t)(i / row_floats);
+        const unsigned long long x = i - (unsigned long long)y * row_floats;
+        const uint32_t band = y / band_rows, rank = band % world, local = (band / world) * band_rows + y % band_rows;
+        full[i] = recv[((unsigned long long)rank * shard_rows + local) * row_floats + x];
+    }
+}
+
 inline unsigned grid_for(unsigned long long n) {
     unsigned long long blocks = (n + kBlock - 1) / kBlock;
     if (blocks > 256ull * 32ull) blocks = 256ull * 32ull;
@@ -219,6 +232,16 @@ mr_status launch_untile(const float *d_slots, float *d_image, uint32_t W, uint32
     const unsigned long long n = (unsigned long long)W * rows * channels;
     if (n == 0) return MR_OK;
     hipLaunchKernelGGL(untile_kernel, dim3(grid_for(n)), dim3(kBlock), 0, stream, d_slots, d_image, W, rows, tile_shape(spp), channels);
+    MR_HIP_CHECK(hipGetLastError());
+    return MR_OK;
+}
+
+mr_status launch_deinterleave(const float *d_recv, float *d_full, uint32_t W, uint32_t H, uint32_t band_rows, uint32_t world,
+                              uint32_t shard_rows, uint32_t fpp, hipStream_t stream) {
+    const unsigned long long n = (unsigned long long)W * H * fpp;
+    if (n == 0) return MR_OK;
+    hipLaunchKernelGGL(deinterleave_kernel, dim3(grid_for(n)), dim3(kBlock), 0, stream, d_recv, d_full, W, H, band_rows, world,
+                       shard_rows, fpp);
     MR_HIP_CHECK(hipGetLastError());
     return MR_OK;
 }

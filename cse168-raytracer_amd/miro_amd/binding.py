@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "mr_scene_add_sphere", "mr_scene_add_plane",
     "mr_bvh_build", "mr_scene_get_info", "mr_scene_get_mesh", "mr_scene_export_tree",
     "mr_trace", "mr_host_alloc", "mr_host_free", "mr_trace_indirect", "mr_trace_get_stats", "mr_gen_eye_rays", "mr_gen_eye_rays_tiled", "mr_tile_pixel_map", "mr_untile_pixels", "mr_gen_shadow_rays", "mr_hit_attrs",
-    "mr_shade_direct", "mr_render_direct", "mr_gen_path_rays", "mr_tonemap",
+    "mr_shade_direct", "mr_render_direct", "mr_band_locate", "mr_band_rows_of", "mr_deinterleave_bands", "mr_gen_path_rays", "mr_tonemap",
     "mr_scene_set_materials", "mr_shade_accumulate", "mr_gen_secondary_rays",
     "mr_photon_map_create", "mr_photon_map_destroy", "mr_photon_map_store", "mr_photon_map_scale",
     "mr_photon_map_balance", "mr_photon_map_count", "mr_photon_map_export", "mr_irradiance_estimate",
@@ -146,6 +146,9 @@ def load_library(path=None):
     L.mr_scene_add_sphere.argtypes = [vp, f32p, C.c_float, u32p]
     L.mr_scene_add_plane.argtypes = [vp, f32p, f32p, C.c_uint32, u32p]
     L.mr_shade_direct.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, vp, C.POINTER(Light), f32p, C.c_uint32, vp, vp]
+    L.mr_band_locate.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
+    L.mr_band_rows_of.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p]
+    L.mr_deinterleave_bands.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     L.mr_render_direct.argtypes = [vp, C.POINTER(FrameDesc), vp, vp, vp, vp, vp]
     L.mr_tonemap.argtypes = [vp, vp, C.c_uint64, vp, vp]
     L.mr_scene_set_materials.argtypes = [vp, C.POINTER(Material), C.c_uint32, u32p]
@@ -207,6 +210,19 @@ class PinnedArray:
             self.close()
         except Exception:
             pass
+
+
+def band_locate(H, band_rows, world, y):
+    """(rank, row inside that rank's shard) of image row y -- mr_band_locate"""
+    r, l = C.c_uint32(), C.c_uint32()
+    _check(lib().mr_band_locate(H, band_rows, world, y, C.byref(r), C.byref(l)))
+    return r.value, l.value
+
+
+def band_rows_of(H, band_rows, rank, world):
+    n = C.c_uint32()
+    _check(lib().mr_band_rows_of(H, band_rows, rank, world, C.byref(n)))
+    return n.value
 
 
 def tile_pixel_map(W, rows, spp):
@@ -394,6 +410,10 @@ class Scene:
         _check(self.L.mr_gen_path_rays(self.h, d_rays.data_ptr(), d_hits.data_ptr(), ptr(d_weights), ptr(d_pixels), ptr(d_ids),
                                        n, spp, seed, bounce, kinds, d_out_rays.data_ptr(), d_out_weights.data_ptr(),
                                        d_out_pixels.data_ptr(), ptr(d_out_ids), d_count.data_ptr(), _stream_ptr(stream)))
+
+    def deinterleave_bands(self, d_recv, d_full, W, H, band_rows, world, shard_rows, floats_per_pixel=3, stream=None):
+        _check(self.L.mr_deinterleave_bands(self.h, d_recv.data_ptr(), d_full.data_ptr(), W, H, band_rows, world, shard_rows,
+                                            floats_per_pixel, _stream_ptr(stream)))
 
     def render_direct(self, cam, W, H, d_rgb, light_pos, wattage, y0=0, y1=None, bands=None, spp=1, jitter=False, seed=168,
                       tiled=False, flags=0, color=(1.0, 1.0, 1.0), diffuse=(1.0, 1.0, 1.0), d_hits=None, d_shadow_hits=None,

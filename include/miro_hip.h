@@ -244,6 +244,19 @@ typedef struct mr_frame_desc {
 mr_status mr_render_direct(mr_scene *scene, const mr_frame_desc *frame, float *d_rgb, mr_hit *d_hits, mr_hit *d_shadow_hits,
                            uint64_t *d_counts, void *stream);
 
+/* ---- multi-GPU frames: image rows dealt to the devices in interleaved bands -------------------
+ * Bands of band_rows rows are dealt round-robin: band b (rows [b*band_rows, ...)) belongs to rank b % world and is that
+ * rank's band number b / world; a rank keeps its rows in band order.  mr_band_locate answers, for image row y, which
+ * rank owns it and where it sits in that rank's shard; mr_band_rows_of counts a rank's rows (host arithmetic, no device).
+ * The reference hands rows to OpenMP workers two at a time (`schedule(dynamic, 2)`, Scene.cpp:113). */
+mr_status mr_band_locate(uint32_t H, uint32_t band_rows, uint32_t world, uint32_t y, uint32_t *rank, uint32_t *local_row);
+mr_status mr_band_rows_of(uint32_t H, uint32_t band_rows, uint32_t rank, uint32_t world, uint32_t *rows);
+/* The de-interleave after the frame's single gather, on the device: d_recv holds `world` shards of shard_rows rows each
+ * (shard_rows >= the largest rank's row count; rows of W pixels, floats_per_pixel floats per pixel: 3 for the float
+ * framebuffer, 4 * spp for mr_hit records); row y of d_full (H rows) is copied from its owner's shard. */
+mr_status mr_deinterleave_bands(mr_scene *scene, const float *d_recv, float *d_full, uint32_t W, uint32_t H, uint32_t band_rows,
+                                uint32_t world, uint32_t shard_rows, uint32_t floats_per_pixel, void *stream);
+
 /* ---- specular materials and secondary rays ("next" row: Scene::traceScene's recursion, Scene.cpp:302-336) -------- */
 typedef struct mr_material {                          /* Phong(kd, ks, kt, shininess, refractIndex), Phong.h:10-14 */
     float diffuse[3], specular[3], transmission[3], shininess, refract_index;

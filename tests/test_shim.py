@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from helpers import camera_of, oracle_scene
+from helpers import camera_of, oracle_scene, product_scene
 from miro_amd import scenes
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -107,6 +107,97 @@ def build_abi_frame(tmp_path, miro):
            "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
     subprocess.check_call(cmd)
     return exe
+
+
+def build_abi_frame_multi(tmp_path, miro):
+    exe = str(tmp_path / "abi_frame_multi")
+    lib_dir = os.path.dirname(miro.lib_path())
+    cmd = ["g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+           "-I", "/opt/rocm/include", os.path.join(ROOT, "tests", "cpp", "abi_frame_multi.cpp"),
+           "-L", lib_dir, "-lmiro_hip", "-L", "/opt/rocm/lib", "-lamdhip64", "-lrccl",
+           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_c_abi_multi_gpu_frame_program_compiles_with_plain_gxx(tmp_path, miro):
+    """SURVEY.md section 8e as a C++ program: one process, a scene replica and one mr_render_direct launch per device,
+    ncclCommInitAll + one ncclGather + mr_deinterleave_bands (g++, the header, the library, HIP runtime, librccl)."""
+    exe = build_abi_frame_multi(tmp_path, miro)
+    assert subprocess.run([exe], capture_output=True).returncode == 2          # usage
+
+
+@pytest.mark.parametrize("H,band,world", [(1080, 5, 8), (1080, 6, 4), (1080, 8, 1), (37, 8, 4), (5, 8, 8), (1080, 16, 3), (64, 1, 7)])
+def test_band_arithmetic_of_the_c_abi_matches_the_python_sharding(miro, H, band, world):
+    """mr_band_locate / mr_band_rows_of (what abi_frame_multi and the device de-interleave use) against frame.band_rows
+    (what bench.py's ranks use): every image row has exactly one owner, rows keep their order inside a shard."""
+    from miro_amd import frame as mframe
+    owner = {}
+    for r in range(world):
+        rows = mframe.rows_of(mframe.band_rows(H, band, r, world))
+        assert miro.band_rows_of(H, band, r, world) == len(rows)
+        for local, y in enumerate(rows):
+            owner[int(y)] = (r, local)
+    assert sorted(owner) == list(range(H))
+    for y in range(H):
+        assert miro.band_locate(H, band, world, y) == owner[y]
+    with pytest.raises(miro.MiroError):
+        miro.band_locate(H, band, world, H)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,band,world,fpp", [(54, 96, 6, 4, 3), (37, 5, 8, 4, 3), (1080, 64, 5, 8, 3), (20, 7, 3, 2, 8)])
+def test_deinterleave_bands_on_the_device(miro, H, W, band, world, fpp):
+    """mr_deinterleave_bands = FrameGather's row permutation: shards filled with (row, column, channel) codes."""
+    import torch
+    from miro_amd import frame as mframe
+    sc = product_scene(miro, "teapot")
+    counts = [miro.band_rows_of(H, band, r, world) for r in range(world)]
+    shard_rows = max(counts) + 1                                               # padded shards
+    recv = torch.full((world, shard_rows, W, fpp), -1.0, dtype=torch.float32, device="cuda")
+    want = torch.empty((H, W, fpp), dtype=torch.float32, device="cuda")
+    code = (torch.arange(W, device="cuda", dtype=torch.float32)[:, None] * 16 + torch.arange(fpp, device="cuda", dtype=torch.float32)[None, :])
+    for r in range(world):
+        for local, y in enumerate(mframe.rows_of(mframe.band_rows(H, band, r, world))):
+            recv[r, local] = code + float(y) * 4096
+            want[int(y)] = code + float(y) * 4096
+    full = torch.zeros((H, W, fpp), dtype=torch.float32, device="cuda")
+    sc.deinterleave_bands(recv, full, W, H, band, world, shard_rows, fpp)
+    torch.cuda.synchronize()
+    assert torch.equal(full, want)
+    with pytest.raises(miro.MiroError):
+        sc.deinterleave_bands(recv, full, W, H, band, world, max(counts) - 1, fpp)
+
+
+@pytest.mark.gpu
+def test_c_abi_multi_gpu_frame_program_on_one_device_equals_abi_frame(tmp_path, miro):
+    """abi_frame_multi with one device: the fused launch, a one-rank ncclGather and the device de-interleave give
+    abi_frame's file byte for byte (five batched kernels there); the hit-record mode gathers the frame's mr_hit buffer."""
+    import torch
+    from miro_amd import frame as mframe
+    exe1, exen = build_abi_frame(tmp_path, miro), build_abi_frame_multi(tmp_path, miro)
+    d = scenes.SCENES["teapot"]
+    W, H, spp = 160, 120, 2
+    csv = lambda v: ",".join(str(float(x)) for x in v)
+    floor = ",".join(str(float(x)) for tri in d["floor"] for x in tri)
+    common = [scenes._model("teapot.obj"), floor, str(W), str(H), str(spp), csv(d["eye"]), csv(d["lookat"]), str(d["fov"]),
+              csv(d["light"]), str(d["wattage"])]
+    a, b, c = str(tmp_path / "one.ppm"), str(tmp_path / "multi.ppm"), str(tmp_path / "multi.hits")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r1 = subprocess.run([exe1] + common + [a], capture_output=True, text=True)
+    r2 = subprocess.run([exen] + common + [b, "1"], capture_output=True, text=True, env=env)
+    assert r1.returncode == 0 and r2.returncode == 0, r1.stderr + r2.stderr + r2.stdout
+    assert open(a, "rb").read() == open(b, "rb").read()
+    rays_line = lambda out: [l for l in out.splitlines() if l.startswith("rays ")]     # RCCL prints a banner of its own
+    assert rays_line(r1.stdout) == rays_line(r2.stdout) and len(rays_line(r1.stdout)) == 1
+    r3 = subprocess.run([exen] + common + [c, "1", "0", "hits"], capture_output=True, text=True, env=env)
+    assert r3.returncode == 0, r3.stderr + r3.stdout
+    got = np.fromfile(c, np.float32).reshape(-1, 4)
+    fr = mframe.FrameRenderer(product_scene(miro, "teapot"), "teapot", W, H, spp=spp)
+    fr.generate()
+    fr.trace_primary()
+    torch.cuda.synchronize()
+    assert np.array_equal(got.view(np.uint32), fr.d_hits.cpu().numpy().view(np.uint32))
 
 
 def test_c_abi_frame_program_compiles_with_plain_gxx(tmp_path, miro):
