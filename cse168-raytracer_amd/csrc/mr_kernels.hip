@@ -371,7 +371,7 @@ static mr_status launch_product(const TraceParams &p, hipStream_t stream) {
 // MR_MATH_PRODUCT: min/max slabs on (corner - o) * (1/d), while-while, wave-uniform nodes through the scalar cache
 template <bool ANY>
 static mr_status launch_product(const TraceParams &p, hipStream_t stream) {
-    return launch_trace_t<true, ANY, false, 11>(p, stream);
+    return launch_trace_t<true, ANY, false, 267>(p, stream);
 }
 #endif
 
@@ -411,8 +411,8 @@ mr_status launch_trace(const TraceParams &p, uint32_t flags, hipStream_t stream)
     }
     // MR_MATH_PRODUCT: slab distances as products with the rounded 1/d (and its development variants)
     if (product) return any ? launch_product<true>(p, stream) : launch_product<false>(p, stream);
-    // default: the reference's quotients by the correction step, while-while, scalar path (VAR 16 | 2 | 8)
-    return any ? launch_trace_t<true, true, false, 26>(p, stream) : launch_trace_t<true, false, false, 26>(p, stream);
+    // default: the reference's quotients by the correction step, while-while, scalar path, octant-specialised (VAR 16 | 2 | 8 | 256)
+    return any ? launch_trace_t<true, true, false, 282>(p, stream) : launch_trace_t<true, false, false, 282>(p, stream);
 }
 
 mr_status launch_eye_rays(const mr_camera &cam, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,

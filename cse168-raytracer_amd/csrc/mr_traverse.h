@@ -129,6 +129,33 @@ __device__ __forceinline__ void slab_box_exactq(float lox, float hix, float loy,
     mx = vmin3(vmax2(ax, bx), vmax2(ay, by), vmax2(az, bz));
 }
 
+// Octant-specialised forms (OCT bit k set: the ray's direction component k is negative; the octant is uniform over the
+// wave).  Rounding is monotone -- RN(a * inv), fma(c, inv, n) and the correctly rounded quotient all grow with the corner
+// when 1/d > 0 and shrink when 1/d < 0 -- and a box has lo <= hi on every axis (boxes that do not are "irregular" and take
+// another path), so the smaller of an axis' two slab distances is the one of the lo corner for d > 0 and of the hi corner
+// for d < 0: the six per-box min/max of the generic forms become a compile-time choice of operand.  Same entry / exit
+// values (up to the sign of a zero), 12 VALU fewer per two-child visit.
+template <int OCT, int SLAB>
+__device__ __forceinline__ void slab_box_oct(float lox, float hix, float loy, float hiy, float loz, float hiz,
+                                             const RayRegs &r, float &mn, float &mx) {
+    const float nx = (OCT & 1) ? hix : lox, fx = (OCT & 1) ? lox : hix;
+    const float ny = (OCT & 2) ? hiy : loy, fy = (OCT & 2) ? loy : hiy;
+    const float nz = (OCT & 4) ? hiz : loz, fz = (OCT & 4) ? loz : hiz;
+    if (SLAB == 4) {
+        mn = vmax3(exact_quot(nx - r.ox, r.dx, r.ix), exact_quot(ny - r.oy, r.dy, r.iy), exact_quot(nz - r.oz, r.dz, r.iz));
+        mx = vmin3(exact_quot(fx - r.ox, r.dx, r.ix), exact_quot(fy - r.oy, r.dy, r.iy), exact_quot(fz - r.oz, r.dz, r.iz));
+    } else if (SLAB == 2) {
+        mn = vmax3(fmaf(nx, r.ix, r.nox), fmaf(ny, r.iy, r.noy), fmaf(nz, r.iz, r.noz));
+        mx = vmin3(fmaf(fx, r.ix, r.nox), fmaf(fy, r.iy, r.noy), fmaf(fz, r.iz, r.noz));
+    } else {
+        mn = vmax3((nx - r.ox) * r.ix, (ny - r.oy) * r.iy, (nz - r.oz) * r.iz);
+        mx = vmin3((fx - r.ox) * r.ix, (fy - r.oy) * r.iy, (fz - r.oz) * r.iz);
+    }
+}
+__device__ __forceinline__ int octant_of(const RayRegs &r) {
+    return (r.dx < 0.0f ? 1 : 0) | (r.dy < 0.0f ? 2 : 0) | (r.dz < 0.0f ? 4 : 0);
+}
+
 // magnitudes for which exact_quot is safe: direction components in [2^-40, 2^40], origin components 0 or in
 // [2^-36, 2^60] (node corners obey the same bound when the node record's flag is clear, mr_api.cpp), so that a non-zero
 // corner - o is at least 2^-59 and every intermediate stays a normal number
@@ -258,7 +285,7 @@ __device__ __forceinline__ v16f load_node_scalar(const float4 *nodes, int cur_un
     return v;
 }
 
-template <bool EXACT, bool STATS, int SLAB>
+template <bool EXACT, bool STATS, int SLAB, int OCT = 8>
 __device__ __forceinline__ void node_slabs(const float4 q0, const float4 q1, const float4 q2, const RayRegs &r,
                                            float &mn0, float &mx0, float &mn1, float &mx1);
 
@@ -294,7 +321,7 @@ __device__ __forceinline__ void node_decide(float mn0, float mx0, float mn1, flo
 // SLAB: 0 = select form (the reference's NaN semantics) on (corner - o) * (1/d), 1 = min/max on the same products,
 //       2 = lean fma form, 3 = select form on the reference's true quotients (corner - o) / d
 // SCALAR: try the wave-uniform scalar-load path first
-template <bool EXACT, bool STATS, int SLAB, bool SCALAR = false>
+template <bool EXACT, bool STATS, int SLAB, bool SCALAR = false, int OCT = 8>
 __device__ __forceinline__ void node_step(const TraceParams &p, const RayRegs &r, Lane &L, int *s_stack, int tid, Stats &st) {
     float mn0, mx0, mn1, mx1;
     constexpr bool kSafe = SLAB == 1 || SLAB == 2 || SLAB == 4;
@@ -309,7 +336,7 @@ __device__ __forceinline__ void node_step(const TraceParams &p, const RayRegs &r
                 node_decide<STATS, false>(mn0, mx0, mn1, mx1, __float_as_int(v[12]), __float_as_int(v[13]), r, L, s_stack, st);
                 return;
             }
-            node_slabs<EXACT, STATS, SLAB>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
+            node_slabs<EXACT, STATS, SLAB, OCT>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
             node_decide<STATS, kSafe>(mn0, mx0, mn1, mx1, __float_as_int(v[12]), __float_as_int(v[13]), r, L, s_stack, st);
             return;
         }
@@ -323,14 +350,17 @@ __device__ __forceinline__ void node_step(const TraceParams &p, const RayRegs &r
         node_decide<STATS, false>(mn0, mx0, mn1, mx1, q3.x, q3.y, r, L, s_stack, st);
         return;
     }
-    node_slabs<EXACT, STATS, SLAB>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
+    node_slabs<EXACT, STATS, SLAB, OCT>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
     node_decide<STATS, kSafe>(mn0, mx0, mn1, mx1, q3.x, q3.y, r, L, s_stack, st);
 }
 
-template <bool EXACT, bool STATS, int SLAB>
+template <bool EXACT, bool STATS, int SLAB, int OCT>
 __device__ __forceinline__ void node_slabs(const float4 q0, const float4 q1, const float4 q2, const RayRegs &r,
                                            float &mn0, float &mx0, float &mn1, float &mx1) {
-    if (SLAB == 2) {
+    if (OCT < 8 && (SLAB == 1 || SLAB == 2 || SLAB == 4)) {
+        slab_box_oct<OCT, SLAB>(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, r, mn0, mx0);
+        slab_box_oct<OCT, SLAB>(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, r, mn1, mx1);
+    } else if (SLAB == 2) {
         slab_box_lean(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, r, mn0, mx0);
         slab_box_lean(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, r, mn1, mx1);
     } else if (SLAB == 4) {
@@ -488,7 +518,7 @@ __device__ __forceinline__ void tri_step(const TraceParams &p, const RayRegs &r,
 //         long as its slowest lane's search for a leaf (incoherent batches: 14 of 64 lanes active per VALU
 //         instruction, profiles/r02_before_random); with the vote at least half of the unfinished lanes are active in every step.  The order of
 //         every lane's own steps -- and so its hit record -- is the same in all three modes.
-template <bool EXACT, bool ANY, bool STATS, int SLAB, int MODE, bool SCALAR, bool OBJ = false>
+template <bool EXACT, bool ANY, bool STATS, int SLAB, int MODE, bool SCALAR, bool OBJ = false, int OCT = 8>
 __device__ __forceinline__ void traverse(const TraceParams &p, const RayRegs &r, Lane &L, int *s_stack, int tid, Stats &st) {
     if (MODE == 2) {
         L.lpos = 0; L.lend = 0;
@@ -497,14 +527,14 @@ __device__ __forceinline__ void traverse(const TraceParams &p, const RayRegs &r,
             const unsigned long long m_node = __ballot(want_node), m_tri = __ballot(want_tri);
             if ((m_node | m_tri) == 0ull) break;
             if (__popcll(m_node) >= __popcll(m_tri)) {
-                if (want_node) node_step<EXACT, STATS, SLAB, SCALAR>(p, r, L, s_stack, tid, st);
+                if (want_node) node_step<EXACT, STATS, SLAB, SCALAR, OCT>(p, r, L, s_stack, tid, st);
             } else {
                 if (want_tri) tri_step<EXACT, ANY, STATS, SCALAR, OBJ>(p, r, L, s_stack, st);
             }
         }
     } else if (MODE == 1) {
         while (__any(L.have())) {
-            while (L.cur >= 0) node_step<EXACT, STATS, SLAB, SCALAR>(p, r, L, s_stack, tid, st);
+            while (L.cur >= 0) node_step<EXACT, STATS, SLAB, SCALAR, OCT>(p, r, L, s_stack, tid, st);
             if (L.have()) leaf_step<EXACT, ANY, STATS, SCALAR, OBJ>(p, r, L, s_stack, tid, st);
         }
     } else {
@@ -522,7 +552,8 @@ __device__ __forceinline__ void traverse(const TraceParams &p, const RayRegs &r,
 // VAR bit 0: min/max slabs on the products (corner - o) * (1/d) for waves that cannot produce a NaN;
 //     bit 1: while-while control flow (bit 6: the voting control flow instead); bit 2: lean fma slabs (MR_MATH_FAST); bit 3: wave-uniform nodes and leaves
 //     through the scalar cache; bit 4: every slab distance is the reference's true quotient (the default trace;
-//     MR_COUNT_STATS implies it); bit 5: the scene holds spheres and / or planes.
+//     MR_COUNT_STATS implies it); bit 5: the scene holds spheres and / or planes; bit 8: octant-specialised slab tests
+//     for waves whose rays share an octant.
 // ---------------------------------------------------------------------------------------------------
 template <bool EXACT, bool ANY, bool STATS, int VAR>
 __device__ __forceinline__ void trace_ray(const TraceParams &p, const RayRegs &r, float tmax0, bool live, Lane &L,
@@ -548,16 +579,43 @@ __device__ __forceinline__ void trace_ray(const TraceParams &p, const RayRegs &r
         L.cur = (live && !((mn > mx) || (mn > tmax0) || (mx < r.tmin))) ? p.root_ref : kDone;
     }
 
-    if (kMinMax) {
+    // VAR bit 8: when the wave's live rays all point into one octant the slab tests take their near / far corners by
+    // position (slab_box_oct): eight copies of the loop, chosen once per ray batch of the wave
+    constexpr bool kOct = (VAR & 256) != 0;
+    constexpr int kGoodSlab = kMinMax ? kSafeSlab : 4;
+    const bool good_wave = kMinMax ? __all(lane_is_nan_free(r) || !live) : ((kStrict && !STATS) ? __all(lane_is_regular(r) || !live) : false);
+    bool done_oct = false;
+    if (kOct && (kMinMax || (kStrict && !STATS)) && good_wave) {
+        const unsigned long long m_live = __ballot(live);
+        if (m_live) {
+            const int oct = octant_of(r);
+            const int oct0 = __builtin_amdgcn_readlane(oct, __ffsll((long long)m_live) - 1);
+            if (__all(!live || oct == oct0)) {
+                done_oct = true;
+                switch (oct0) {
+                    case 0: traverse<EXACT, ANY, STATS, kGoodSlab, kWW, kScalar, kObj, 0>(p, r, L, s_stack, tid, st); break;
+                    case 1: traverse<EXACT, ANY, STATS, kGoodSlab, kWW, kScalar, kObj, 1>(p, r, L, s_stack, tid, st); break;
+                    case 2: traverse<EXACT, ANY, STATS, kGoodSlab, kWW, kScalar, kObj, 2>(p, r, L, s_stack, tid, st); break;
+                    case 3: traverse<EXACT, ANY, STATS, kGoodSlab, kWW, kScalar, kObj, 3>(p, r, L, s_stack, tid, st); break;
+                    case 4: traverse<EXACT, ANY, STATS, kGoodSlab, kWW, kScalar, kObj, 4>(p, r, L, s_stack, tid, st); break;
+                    case 5: traverse<EXACT, ANY, STATS, kGoodSlab, kWW, kScalar, kObj, 5>(p, r, L, s_stack, tid, st); break;
+                    case 6: traverse<EXACT, ANY, STATS, kGoodSlab, kWW, kScalar, kObj, 6>(p, r, L, s_stack, tid, st); break;
+                    default: traverse<EXACT, ANY, STATS, kGoodSlab, kWW, kScalar, kObj, 7>(p, r, L, s_stack, tid, st); break;
+                }
+            }
+        }
+    }
+    if (done_oct) {
+    } else if (kMinMax) {
         // a slab product (corner - o) * (1/d) can only be NaN as 0*inf or inf*0 or from a non-finite origin:
         // with o, d and 1/d all finite in every lane the select form and the min/max form decide identically
-        if (__all(lane_is_nan_free(r) || !live)) traverse<EXACT, ANY, STATS, kSafeSlab, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
+        if (good_wave) traverse<EXACT, ANY, STATS, kSafeSlab, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
         else traverse<EXACT, ANY, STATS, 0, kWW, false, kObj>(p, r, L, s_stack, tid, st);
     } else if (kStrict && !STATS) {
         // the default trace: exact quotients by the correction step where every lane's ray is regular (then the lanes'
         // quotients are NaN-free too and the min/max form decides like the select form); the reference's own
         // divisions otherwise
-        if (__all(lane_is_regular(r) || !live)) traverse<EXACT, ANY, STATS, 4, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
+        if (good_wave) traverse<EXACT, ANY, STATS, 4, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
         else traverse<EXACT, ANY, STATS, 3, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
     } else {
         traverse<EXACT, ANY, STATS, kBaseSlab, kWW, kStrict && kScalar, kObj>(p, r, L, s_stack, tid, st);

@@ -219,6 +219,35 @@ def test_stats_counters_match_reference(oracle, miro, torch_cuda, golden_dir, na
     assert (primary[0] + pr[0] + shc[0], primary[1] + pr[1] + shc[1]) == (k["shadows"]["box_tests"], k["shadows"]["tri_tests"])
 
 
+def test_published_sse_triangle_counts_belong_to_the_sse_traversal(oracle, miro, torch_cuda, golden_dir):
+    """can the DEVICE reproduce the write-up's 892 848 / 1 817 141 ray-triangle tests (Readme.tex:95,99)?
+    No, and this test pins why.  Those numbers come from the reference's SSE build: 8 triangles per leaf AND the packet
+    traversal of BVH.cpp:513-584 (12-bit _mm_rcp_ps slab distances, strict comparisons, children culled against the
+    running minHit.t, triangles counted per 4-wide packet).  The device implements the SCALAR traversal north_star names
+    (BVH.cpp:587-651): on the very same 8-per-leaf tree it visits what the oracle's scalar traversal visits -- 987 237
+    triangle tests for the teapot's primary rays, not 892 848 -- so the count is a property of the SSE control flow, which
+    exists only as the timed CPU baseline (oracle/miro_oracle_sse.c; it reproduces both published numbers to the unit in
+    tests/test_oracle_kat.py::test_writeup_table_teapot_sse).  What the device must and does reproduce is every counter of
+    the scalar traversal, on this tree as on the 4-per-leaf one."""
+    k = json.load(open(os.path.join(golden_dir, "kat_counters.json")))["writeup"]["teapot_sse"]
+    name = "teapot"
+    a = oracle_scene(oracle, name, 8)
+    b = product_scene(miro, name, 8)
+    assert (b.info().n_nodes, b.info().n_leaves) == (k["nodes"], k["leaves"])          # 199 / 100: the published tree
+    rays = oracle.eye_rays(camera_of(oracle, name), 512, 512)
+    want_hits, want = a.trace(rays, counters=True)
+    b.stats()
+    hits = b.trace(rays.view(miro.RAY_DTYPE), miro.MR_COUNT_STATS)
+    got = b.stats()
+    assert hits.tobytes() == want_hits.tobytes()
+    assert tuple(got) == tuple(want) == (1505697, 987237)
+    # The SSE count is not even a property of the algorithm alone: _mm_rcp_ps is an approximation whose table differs between
+    # CPU families -- this container's host reproduces the write-up's 892 848 to the unit (tests/test_oracle_kat.py, CPU
+    # suite), the GPU box's EPYC counts 893 330 for the same rays.  Either way it is not the scalar traversal's count.
+    _, _, sse = a.trace_sse(rays, threads=1, counters=True)
+    assert k["no_shadows"]["tri_tests"] == 892848 and abs(sse[1] - 892848) < 2000 and sse[1] != got[1]
+
+
 # ----------------------------------------------------------------------------------------------- fast mode
 @pytest.mark.parametrize("name", ["cornell", "teapot", "bunny", "sponza"])
 def test_fast_math_within_tolerance(oracle, miro, torch_cuda, name):
