@@ -7,7 +7,7 @@
 # usage: tools/collect_profiles.sh <tag> [bench args...]
 set -o pipefail
 TAG=${1:-r01}; shift
-ARGS=${@:-"--steps 3 --warmup 1 --no-cpu-baseline"}
+ARGS=${@:-"--steps 3 --warmup 1 --no-cpu-baseline --no-pmc"}   # --no-pmc: bench.py must not start its own rocprofv3 child under the profiler
 OUT=gpurun_out/prof_${TAG}
 rm -rf "$OUT"
 mkdir -p "$OUT"

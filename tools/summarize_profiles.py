@@ -19,7 +19,7 @@ def find(d, pat):
 
 
 def short(name):
-    m = re.search(r"(trace_kernel<[^>]*>|[a-z_]+_kernel)", name)
+    m = re.search(r"((?:trace|frame|trace_persistent)_kernel<[^>]*>|[a-z_]+_kernel)", name)
     return m.group(1) if m else name[:60]
 
 
@@ -77,8 +77,39 @@ def main():
                                                "%.1f" % (sum(f) / len(f)) if f else "-", "%.1f" % (sum(w) / len(w)) if w else "-"))
 
     traffic = None
+    frame_k = [k for k in kernels if k.startswith("frame_kernel<")]
+    if bench_line and frame_k and fetch.get(frame_k[0]) and write.get(frame_k[0]):
+        # round 2: the whole step is one launch of frame_kernel; nothing streams through HBM but the 12-byte pixels
+        k = frame_k[0]
+        cfg = bench_line["config"]
+        f = [x for x in fetch[k] if x > 0.5 * max(fetch[k])]
+        w = [x for x in write[k] if x > 0.5 * max(write[k])]
+        fetch_bytes = sum(f) / len(f) * 1024.0 * 2.0
+        write_bytes = sum(w) / len(w) * 1024.0
+        avg_ms = None
+        for r in rows:
+            if short(r["Name"]) == k:
+                avg_ms = float(r["AverageNs"]) / 1e6
+        traffic = {
+            "workload": cfg["workload"], "tag": tag, "kernel": k,
+            "fetch_size_kib_raw": sum(f) / len(f), "write_size_kib_raw": sum(w) / len(w), "fetch_correction": 2.0,
+            "hbm_bytes_per_launch": fetch_bytes + write_bytes,
+            "hbm_bytes_per_ray": (fetch_bytes + write_bytes) / cfg["rays_per_step"],
+            "framebuffer_bytes_per_launch": 12.0 * cfg["rays_per_step"] / 2.0 / 64.0 if "64spp" in cfg["workload"] else None,
+            "kernel_trace_avg_ms": avg_ms,
+        }
+        with open(os.path.join(pdir, "%s_traffic.json" % tag), "w") as out:
+            json.dump(traffic, out, indent=1)
+        md += ["", "## HBM traffic of the frame kernel", "",
+               "FETCH_SIZE x 2 (gfx950 reports half of a wide coalesced read stream) + WRITE_SIZE per launch (= per step of "
+               "%d rays): **%.1f MB**, %.3f B per ray -- the kernel keeps rays and hits in registers; what reaches HBM is the "
+               "float framebuffer and the first touch of the 5 MB scene." % (cfg["rays_per_step"], traffic["hbm_bytes_per_launch"] / 1e6,
+                                                                                traffic["hbm_bytes_per_ray"])]
+        if avg_ms:
+            md += ["", "kernel-trace average duration of `%s`: %.4f ms (the bench line's roofline.avg_launch_ms, from HIP events in the "
+                   "same run: %s)" % (k, avg_ms, json.dumps(bench_line["roofline"].get("avg_launch_ms")))]
     main_k = [k for k in kernels if k.startswith("trace_kernel<true, false, false")]
-    if bench_line and main_k and fetch.get(main_k[0]) and write.get(main_k[0]):
+    if not traffic and bench_line and main_k and fetch.get(main_k[0]) and write.get(main_k[0]):
         k = main_k[0]
         cfg = bench_line["config"]
         # the timed launches are the big ones; the STATS pre-pass uses another template instance
