@@ -226,18 +226,16 @@ class FrameRenderer:
         self.scene.trace_indirect(self.d_shadow_rays, self.d_count, self.n, self.d_shadow_hits, fl, stream=stream)
 
     def _untile(self, stream=None):
-        """slot order -> image order (a no-op for frames generated in image order)"""
+        """slot order -> image order (a no-op for frames generated in image order): the library's own scatter, band by
+        band, on the caller's stream (whatever kind of handle it is)"""
         if not self.tiled:
             return
-        if len(self.bands) == 1:            # one window: the library's own scatter, on the caller's stream
-            y0, y1 = self.bands[0]
-            self.scene.untile_pixels(self.d_slots, self.d_rgb, self.W, y1 - y0, self.spp, channels=3, stream=stream)
-            return
-        if isinstance(stream, torch.cuda.Stream):
-            with torch.cuda.stream(stream):
-                self.d_rgb.index_copy_(0, self.d_slot_pixel, self.d_slots)
-        else:
-            self.d_rgb.index_copy_(0, self.d_slot_pixel, self.d_slots)
+        off = 0
+        for y0, y1 in self.bands:
+            k = (y1 - y0) * self.W
+            self.scene.untile_pixels(self.d_slots[off:off + k], self.d_rgb[off:off + k], self.W, y1 - y0, self.spp, channels=3,
+                                     stream=stream)
+            off += k
 
     def shade(self, stream=None):
         self.scene.shade_direct(self.d_rays, self.d_hits, self.n, self.d_shadow_hits, self.d_src, self.d_count,
@@ -287,6 +285,13 @@ class FrameRenderer:
         Fresnel / refract children of the next level by ballot compaction.  depth = TRACE_DEPTH (Miro.h:13): rays are
         traced while depth >= 0, i.e. up to depth+1 levels.  Returns the number of rays traced per level."""
         sc, L, W = self.scene, self.desc["light"], self.desc["wattage"]
+        # this driver mixes library launches (on `stream`) with torch ops and .item() read-backs: they only order against
+        # each other on torch's current stream, so `stream` must be that stream (or a torch Stream, made current here)
+        if stream is not None and not isinstance(stream, torch.cuda.Stream):
+            raise TypeError("render_specular: pass a torch.cuda.Stream (or None for the current stream), not a raw handle")
+        if stream is not None and stream != torch.cuda.current_stream(self.device):
+            with torch.cuda.stream(stream):
+                return self.render_specular(depth, stream)
         self.d_slots.zero_()
         rays, weights, pixels, n = self.d_rays, None, None, self.n
         per_level = []
@@ -319,5 +324,8 @@ class FrameRenderer:
         return per_level
 
     def ray_counts(self):
-        """(primary, shadow) of the last step -- synchronises."""
-        return self.n, int(self.d_count.item()) if self.n else 0
+        """(primary, shadow) of the last step -- synchronises the whole device (the step may have run on any stream)."""
+        if not self.n:
+            return 0, 0
+        torch.cuda.synchronize(self.device)
+        return self.n, int(self.d_count.item())
