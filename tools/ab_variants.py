@@ -2,6 +2,9 @@
 (primary batch, shadow batch, incoherent batch).  Each variant runs in its own process (the variant is read
 once from MIRO_TRACE_VARIANT); a position-weighted 64-bit checksum of the hit bits is compared.
 
+NEEDS A DEVELOPMENT BUILD of the library (make -C cse168-raytracer_amd clean && make -C cse168-raytracer_amd DEV=1): the
+shipped library does not read MIRO_TRACE_VARIANT.  tools/ab_modes.py compares the shipped control-flow modes in one process.
+
 usage: python tools/ab_variants.py [--spp 16] [--variants 0,3,7,9,11,q]   (q = the default trace with exact quotients)
 """
 import argparse
