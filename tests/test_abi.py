@@ -64,6 +64,27 @@ def test_argument_errors(miro):
     assert e.value.status == -5
 
 
+def test_round2_entry_points_fail_loudly_without_a_device(miro):
+    """mr_render_direct, mr_gen_path_rays and mr_deinterleave_bands on a host_only scene: MR_ERR_STATE, never a CPU path;
+    the frame descriptor's size is the header's."""
+    from miro_amd import binding
+    assert C.sizeof(binding.FrameDesc) == 40 + 4 * 4 + 3 * 4 + 5 * 4 + 28 + 12 + 16
+    s = miro.Scene()
+    s.add_triangle([0, 0, 0, 1, 0, 0, 0, 1, 0], [0, 0, 1] * 3)
+    s.build(4, host_only=True)
+    L = miro.lib()
+    fd = binding.FrameDesc()
+    fd.W, fd.H, fd.y1, fd.spp = 4, 4, 4, 1
+    dummy = C.c_void_p(16)
+    assert L.mr_render_direct(s.h, C.byref(fd), dummy, None, None, None, None) == -5
+    assert b"CPU" in L.mr_last_error() or b"device" in L.mr_last_error()
+    assert L.mr_gen_path_rays(s.h, dummy, dummy, None, None, None, 4, 1, 1, 0, 7, dummy, dummy, dummy, None, dummy, None) == -5
+    assert L.mr_deinterleave_bands(s.h, dummy, dummy, 4, 4, 2, 2, 2, 3, None) == -5
+    # pure host arithmetic works anywhere
+    assert miro.band_rows_of(10, 4, 0, 2) == 6 and miro.band_rows_of(10, 4, 1, 2) == 4
+    assert miro.band_locate(10, 4, 2, 9) == (0, 5)
+
+
 def test_scene_is_immutable_after_build(miro):
     s = miro.Scene()
     s.add_triangle([0, 0, 0, 1, 0, 0, 0, 1, 0], [0, 0, 1] * 3)
