@@ -145,7 +145,7 @@ def _counter_means(out_dir, kernel_substr):
     return {k: sum(v) / len(v) for k, v in acc.items()}, (max((len(v) for v in acc.values()), default=0))
 
 
-def live_pmc(argv_leg, kernel_substr, timeout_s=200):
+def live_pmc(argv_leg, kernel_substr, timeout_s=120):
     """Three rocprofv3 --pmc passes (SQ counters; FETCH_SIZE; WRITE_SIZE -- the TCC pair does not fit one pass) over
     `python3 bench.py --pmc-leg ...`, i.e. over the same frame this run times.  Returns the counter means per launch of
     the frame kernel, or None when the profiler is missing / fails / times out."""

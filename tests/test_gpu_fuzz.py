@@ -128,6 +128,18 @@ def test_random_scene_bit_exact(oracle, miro, seed):
         # planes in the scene the flag is a no-op and the one-shot kernels answer)
         assert_hits_bit_exact(b.trace(r, flags=miro.MR_TRACE_PERSISTENT), want)
         assert_hits_bit_exact(b.trace(r, flags=miro.MR_TRACE_PERSISTENT | miro.MR_MATH_PRODUCT), prod)
+        # round 2: the voting control flow (alone and with the persistent refill) is the same per-ray sequence of steps
+        assert_hits_bit_exact(b.trace(r, flags=miro.MR_TRACE_INCOHERENT), want)
+        assert_hits_bit_exact(b.trace(r, flags=miro.MR_TRACE_INCOHERENT | miro.MR_TRACE_PERSISTENT), want)
+        assert_hits_bit_exact(b.trace(r, flags=miro.MR_TRACE_INCOHERENT | miro.MR_MATH_PRODUCT), prod)
+        # round 2: the octant-specialised slab tests only run when a whole wave's rays point into one octant, which random
+        # batches almost never do: trace the same rays grouped by octant (a permutation, answers are per ray) so that
+        # they do, in both arithmetic modes
+        octant = (rays["dx"] < 0).astype(np.int32) | ((rays["dy"] < 0).astype(np.int32) << 1) | ((rays["dz"] < 0).astype(np.int32) << 2)
+        order = np.argsort(octant, kind="stable")
+        grouped = np.ascontiguousarray(r[order])
+        assert_hits_bit_exact(b.trace(grouped), want[order])
+        assert_hits_bit_exact(b.trace(grouped, flags=miro.MR_MATH_PRODUCT), prod[order])
         if diff and os.environ.get("MIRO_FUZZ_VERBOSE"):
             print(f"seed {seed} round {rnd}: product form differs on {diff} of {len(rays)} rays")
         if rnd == 0:
