@@ -304,9 +304,12 @@ class FrameRenderer:
             sh_hits = torch.empty((n, 4), **f32)
             src = torch.empty(n, dtype=torch.int32, device=self.device)
             cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
-            sc.trace_device(rays, n, hits, self.flags, stream=stream)
+            # bounce queues are compacted in wave order, not in image order: from the first bounce on the batches carry the
+            # MR_TRACE_INCOHERENT hint (voting control flow; the same hit records)
+            fl = self.flags | (binding.MR_TRACE_INCOHERENT if level > 0 else 0)
+            sc.trace_device(rays, n, hits, fl, stream=stream)
             sc.gen_shadow_rays(rays, hits, n, L, sh_rays, src, cnt, stream=stream)
-            sc.trace_indirect(sh_rays, cnt, n, sh_hits, self.flags, stream=stream)       # closest hit: the occluder matters
+            sc.trace_indirect(sh_rays, cnt, n, sh_hits, fl, stream=stream)               # closest hit: the occluder matters
             sc.shade_accumulate(rays, hits, weights, pixels, n, sh_rays, sh_hits, src, cnt, L, W, self.d_slots,
                                 spp=self.spp, stream=stream)
             n_shadow = int(cnt.item())
