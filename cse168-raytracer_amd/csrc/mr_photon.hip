@@ -129,12 +129,15 @@ __device__ __forceinline__ float compress(WaveLds &w, int &count, int k, int lan
 // to the first overflow: near child first, the far child if the splitting plane is inside max_dist, the node itself
 // after both.  No stack: the path is implicit in the heap index, and whether a child was the near one is kept as one bit
 // per level.  Returns the index of the farthest of the first k candidates (earliest among equals) once candidate k+1
-// has been seen; 0 when the whole (reachable) tree holds at most k candidates.
+// has been seen; 0 when the whole (reachable) tree holds at most k candidates.  radius_after = the reference's np->dist2[0]
+// right after that replacement: the largest distance among the first k+1 candidates without m* -- every later
+// replacement only shrinks it, so the cooperative search may start from it instead of from max_dist^2.
 __device__ __forceinline__ int first_overflow(const PhotonMapDev &pm, float qx, float qy, float qz, float nx, float ny, float nz,
-                                              float md2, int k) {
+                                              float md2, int k, float &radius_after) {
+    radius_after = md2;
     if (pm.n < 1) return 0;
     int i = 1, cnt = 0, best_i = 0;
-    float best_d2 = -1.0f;
+    float best_d2 = -1.0f, second_d2 = -1.0f;
     unsigned near_right = 0;              // bit d: at the ancestor of depth d the near child was the right one
     bool descend = true;
     while (true) {
@@ -157,8 +160,12 @@ __device__ __forceinline__ int first_overflow(const PhotonMapDev &pm, float qx, 
             dd = A.z - qz; d2 += dd * dd;
             const float facing = (D.x * nx + D.y * ny) + D.z * nz;
             if (d2 < md2 && facing < 0.0f) {
-                if (++cnt > k) return best_i;                               // candidate k+1: the heap root goes (:222-238)
-                if (d2 > best_d2) { best_d2 = d2; best_i = i; }
+                if (++cnt > k) {                                            // candidate k+1: the heap root goes (:222-238)
+                    radius_after = fmaxf(second_d2, d2);
+                    return best_i;
+                }
+                if (d2 > best_d2) { second_d2 = best_d2; best_d2 = d2; best_i = i; }
+                else if (d2 > second_d2) second_d2 = d2;
             }
         }
         // back up: a near child hands over to its far sibling (if the plane is inside the radius), a far child to the parent
@@ -195,18 +202,21 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
     // the wave searches the 64 queries one after the other
     for (unsigned long long base = wave_id * 64ull; base < nq; base += n_waves * 64ull) {
       int my_mstar = 0;
+      float my_radius = md2;
       {
           const unsigned long long qa = base + (unsigned)lane;
           if (qa < nq) {
               const float ax = qnrm[3 * qa];
               if (ax == ax)
-                  my_mstar = first_overflow(pm, qpos[3 * qa], qpos[3 * qa + 1], qpos[3 * qa + 2], ax, qnrm[3 * qa + 1], qnrm[3 * qa + 2], md2, k);
+                  my_mstar = first_overflow(pm, qpos[3 * qa], qpos[3 * qa + 1], qpos[3 * qa + 2], ax, qnrm[3 * qa + 1], qnrm[3 * qa + 2], md2, k,
+                                            my_radius);
           }
       }
       const int n_here = nq - base < 64ull ? (int)(nq - base) : 64;
       for (int t = 0; t < n_here; t++) {
         const unsigned long long q = base + (unsigned)t;
         const int mstar = __shfl(my_mstar, t, 64);            // 0: this query never overflows
+        const float radius0 = __shfl(my_radius, t, 64);
         const float qx = qpos[3 * q], qy = qpos[3 * q + 1], qz = qpos[3 * q + 2];
         const float nx = qnrm[3 * q], ny = qnrm[3 * q + 1], nz = qnrm[3 * q + 2];
         if (nx != nx) {                                       // NaN normal = "no query here" (mr_final_gather: miss / non-diffuse hit)
@@ -217,7 +227,10 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
             }
             continue;
         }
-        float r2 = md2;                                       // np.dist2[0] (PhotonMap.cpp:99)
+        // np.dist2[0]: max_dist^2 (PhotonMap.cpp:99) until the first overflow; for a query that overflows, the reference's
+        // radius right after the overflow bounds everything that can still enter the result -- one ulp is added because the
+        // photon AT that distance is in the set while candidates must be strictly nearer than the radius
+        float r2 = mstar != 0 ? __uint_as_float(__float_as_uint(radius0) + 1u) : md2;
         int count = 0;
         bool evicted = false;
         int sp = 0;
