@@ -133,6 +133,8 @@ class FusedFrame:
         self.tiled = (spp < 64) if tiled is None else bool(tiled)
         f32 = dict(dtype=torch.float32, device=self.device)
         self.d_rgb = torch.zeros((max(self.n_pixels, 1), 3), **f32) if rgb is None else rgb
+        if self.d_rgb.numel() < 3 * self.n_pixels or self.d_rgb.dtype != torch.float32 or not self.d_rgb.is_contiguous():
+            raise ValueError("rgb must be a contiguous float32 buffer of at least %d x 3 values" % self.n_pixels)
         self.d_hits = torch.empty((max(self.n, 1), 4), **f32) if keep_hits else None
         self.d_shadow_hits = torch.empty((max(self.n, 1), 4), **f32) if keep_hits else None
         self.d_counts = torch.zeros(2, dtype=torch.int64, device=self.device)

@@ -99,6 +99,28 @@ def test_fused_frame_of_one_ranks_bands(miro, world, band):
     assert tuple(tot) == whole.ray_counts()
 
 
+@pytest.mark.parametrize("world,band", [(2, 6), (4, 5)])
+def test_fused_hit_records_of_the_ranks_deinterleave_to_the_unsharded_buffer(miro, world, band):
+    """The hit-buffer parity mode of SURVEY section 8e on the fused path: every rank's primary mr_hit records (image order
+    inside its bands, 4*spp floats per pixel), put side by side as the gather would and de-interleaved by
+    mr_deinterleave_bands, are the unsharded frame's hit buffer."""
+    name, W, H, spp = "bunny", 80, 50, 4
+    sc = product_scene(miro, name)
+    whole = mframe.FusedFrame(sc, name, W, H, spp=spp, tiled=False, keep_hits=True)
+    whole.step()
+    counts = [miro.band_rows_of(H, band, r, world) for r in range(world)]
+    shard_rows = max(counts)
+    recv = torch.zeros((world, shard_rows * W, 4 * spp), dtype=torch.float32, device="cuda")
+    for r in range(world):
+        fu = mframe.FusedFrame(sc, name, W, H, spp=spp, band=band, rank=r, world=world, tiled=False, keep_hits=True)
+        fu.step()
+        recv[r, :counts[r] * W] = fu.d_hits.view(counts[r] * W, 4 * spp)
+    full = torch.empty((H * W, 4 * spp), dtype=torch.float32, device="cuda")
+    sc.deinterleave_bands(recv, full, W, H, band, world, shard_rows, 4 * spp)
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits(full.view(-1, 4)), _bits(whole.d_hits))
+
+
 def test_fused_frame_rejects_what_it_cannot_do(miro):
     sc = product_scene(miro, "teapot")
     rgb = torch.zeros((16 * 16, 3), dtype=torch.float32, device="cuda")
