@@ -391,7 +391,7 @@ def main():
                     json.dump(rec, open(os.path.join(ROOT, "gpurun_out", name), "w"), indent=1)
                 except Exception:
                     pass
-        if pmc is None:
+        if pmc is None and fused:        # the committed counters are the frame kernel's: they say nothing about --batched
             rec = committed_pmc(workload)
             if rec:
                 pmc = {k: v * samples_rank0 for k, v in rec["per_sample"].items()}
