@@ -10,8 +10,12 @@
 // mode "hits": gathers the primary mr_hit records instead (16 B per sample, samples in image order) and writes them raw:
 //              the hit-buffer parity mode of SURVEY.md section 8e.
 //
+// A fourth word "virtual" rehearses the N-rank flow on ONE device: every rank's replica, launch and shard live on device 0 and
+// the gather is N device-to-device copies instead of the RCCL call -- everything but the collective itself (band arithmetic,
+// per-rank launches, shard layout, de-interleave) runs exactly as with N devices, which is how the 1-GPU test boxes check it.
+//
 // usage: abi_frame_multi <model.obj> <floor 9 floats | -> <W> <H> <spp> <eye xyz> <lookat xyz> <fov> <light xyz> <wattage>
-//                        <out file> <devices> [band rows = 0: auto] [rgb | hits]
+//                        <out file> <devices> [band rows = 0: auto] [rgb | hits] [virtual]
 // Prints "rays <primary> <shadow>" (totals over the devices) and "band <rows> devices <n>".
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
@@ -52,11 +56,12 @@ int main(int argc, char **argv) {
     const int world = atoi(argv[12]);
     uint32_t band = argc > 13 ? (uint32_t)atoi(argv[13]) : 0;
     const bool hits_mode = argc > 14 && strcmp(argv[14], "hits") == 0;
+    const bool virtual_ranks = argc > 15 && strcmp(argv[15], "virtual") == 0;
     if (world < 1 || W == 0 || H == 0 || spp == 0) return 3;
     if (band == 0) band = auto_band(H, (uint32_t)world);
     int have = 0;
     HIP_OK(hipGetDeviceCount(&have));
-    if (have < world) { fprintf(stderr, "%d devices asked for, %d present\n", world, have); return 6; }
+    if (have < (virtual_ranks ? 1 : world)) { fprintf(stderr, "%d devices asked for, %d present\n", world, have); return 6; }
 
     fd.W = W; fd.H = H; fd.spp = spp; fd.jitter = spp > 1; fd.seed = 168;
     fd.band_rows = band; fd.band_world = (uint32_t)world;
@@ -77,9 +82,9 @@ int main(int argc, char **argv) {
     std::vector<uint64_t *> d_counts((size_t)world, nullptr);
     std::vector<int> devs((size_t)world);
     for (int r = 0; r < world; r++) {
-        devs[(size_t)r] = r;
-        HIP_OK(hipSetDevice(r));
-        MR_OK_(mr_scene_create(r, &scene[(size_t)r]));
+        devs[(size_t)r] = virtual_ranks ? 0 : r;
+        HIP_OK(hipSetDevice(devs[(size_t)r]));
+        MR_OK_(mr_scene_create(devs[(size_t)r], &scene[(size_t)r]));
         uint32_t ntri = 0;
         MR_OK_(mr_scene_add_obj(scene[(size_t)r], model, 0, &ntri));
         if (strcmp(floor_s, "-") != 0) {
@@ -97,12 +102,12 @@ int main(int argc, char **argv) {
         if (hits_mode) HIP_OK(hipMalloc((void **)&d_rgb[(size_t)r], ((size_t)rows[(size_t)r] * W * 3 + 1) * sizeof(float)));
     }
     std::vector<ncclComm_t> comm((size_t)world);
-    NCCL_OK(ncclCommInitAll(comm.data(), world, devs.data()));
+    if (!virtual_ranks) NCCL_OK(ncclCommInitAll(comm.data(), world, devs.data()));
 
     // ---- render: one launch per device, straight into its shard (rgb mode) or with the hit records as the shard
     for (int r = 0; r < world; r++) {
         if (rows[(size_t)r] == 0) continue;
-        HIP_OK(hipSetDevice(r));
+        HIP_OK(hipSetDevice(devs[(size_t)r]));
         mr_frame_desc mine = fd;
         mine.band_rank = (uint32_t)r;
         if (world == 1) { mine.band_world = 1; mine.y0 = 0; mine.y1 = H; }
@@ -117,17 +122,24 @@ int main(int argc, char **argv) {
     HIP_OK(hipSetDevice(0));
     HIP_OK(hipMalloc((void **)&d_recv, (shard_floats ? shard_floats : 1) * (size_t)world * sizeof(float)));
     HIP_OK(hipMalloc((void **)&d_full, (size_t)W * H * fpp * sizeof(float)));
-    NCCL_OK(ncclGroupStart());
-    for (int r = 0; r < world; r++)
-        NCCL_OK(ncclGather(d_shard[(size_t)r], r == 0 ? d_recv : nullptr, shard_floats, ncclFloat, 0, comm[(size_t)r], stream[(size_t)r]));
-    NCCL_OK(ncclGroupEnd());
+    if (virtual_ranks) {
+        for (int r = 0; r < world; r++) {
+            HIP_OK(hipStreamSynchronize(stream[(size_t)r]));
+            HIP_OK(hipMemcpyAsync(d_recv + (size_t)r * shard_floats, d_shard[(size_t)r], shard_floats * sizeof(float), hipMemcpyDeviceToDevice, stream[0]));
+        }
+    } else {
+        NCCL_OK(ncclGroupStart());
+        for (int r = 0; r < world; r++)
+            NCCL_OK(ncclGather(d_shard[(size_t)r], r == 0 ? d_recv : nullptr, shard_floats, ncclFloat, 0, comm[(size_t)r], stream[(size_t)r]));
+        NCCL_OK(ncclGroupEnd());
+    }
     MR_OK_(mr_deinterleave_bands(scene[0], d_recv, d_full, W, H, band, (uint32_t)world, shard_rows, fpp, stream[0]));
 
     // ---- output
     unsigned long long n_primary = 0, n_shadow = 0;
     for (int r = 0; r < world; r++) {
         uint64_t c[2] = {0, 0};
-        HIP_OK(hipSetDevice(r));
+        HIP_OK(hipSetDevice(devs[(size_t)r]));
         HIP_OK(hipMemcpyAsync(c, d_counts[(size_t)r], sizeof(c), hipMemcpyDeviceToHost, stream[(size_t)r]));
         HIP_OK(hipStreamSynchronize(stream[(size_t)r]));
         n_primary += c[0]; n_shadow += c[1];
@@ -157,8 +169,8 @@ int main(int argc, char **argv) {
     printf("band %u devices %d\n", band, world);
 
     for (int r = 0; r < world; r++) {
-        HIP_OK(hipSetDevice(r));
-        ncclCommDestroy(comm[(size_t)r]);
+        HIP_OK(hipSetDevice(devs[(size_t)r]));
+        if (!virtual_ranks) ncclCommDestroy(comm[(size_t)r]);
         hipFree(d_shard[(size_t)r]); hipFree(d_counts[(size_t)r]); hipFree(d_rgb[(size_t)r]);
         hipStreamDestroy(stream[(size_t)r]);
         mr_scene_destroy(scene[(size_t)r]);

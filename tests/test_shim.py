@@ -200,6 +200,33 @@ def test_c_abi_multi_gpu_frame_program_on_one_device_equals_abi_frame(tmp_path, 
     assert np.array_equal(got.view(np.uint32), fr.d_hits.cpu().numpy().view(np.uint32))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,band", [(4, 0), (8, 5), (3, 7)])
+def test_c_abi_multi_gpu_frame_program_with_virtual_ranks(tmp_path, miro, world, band):
+    """The N-rank flow of abi_frame_multi with all ranks on this box's one GPU ("virtual": device-to-device copies stand in
+    for the ncclGather): per-rank band launches, shard layout and the device de-interleave give the one-rank program's
+    picture and hit file byte for byte, for a band height that divides the image and ones that leave ragged shards."""
+    exen = build_abi_frame_multi(tmp_path, miro)
+    d = scenes.SCENES["teapot"]
+    W, H, spp = 160, 120, 2
+    csv = lambda v: ",".join(str(float(x)) for x in v)
+    floor = ",".join(str(float(x)) for tri in d["floor"] for x in tri)
+    common = [scenes._model("teapot.obj"), floor, str(W), str(H), str(spp), csv(d["eye"]), csv(d["lookat"]), str(d["fov"]),
+              csv(d["light"]), str(d["wattage"])]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = {}
+    for mode in ("rgb", "hits"):
+        one, many = str(tmp_path / ("one." + mode)), str(tmp_path / ("many." + mode))
+        r1 = subprocess.run([exen] + common + [one, "1", "0", mode], capture_output=True, text=True, env=env)
+        rn = subprocess.run([exen] + common + [many, str(world), str(band), mode, "virtual"], capture_output=True, text=True, env=env)
+        assert r1.returncode == 0 and rn.returncode == 0, r1.stderr + rn.stderr + rn.stdout
+        assert open(one, "rb").read() == open(many, "rb").read(), mode
+        rays = lambda o: [l for l in o.splitlines() if l.startswith("rays ")]
+        assert rays(r1.stdout) == rays(rn.stdout)
+        out[mode] = rn.stdout
+    assert ("devices %d" % world) in out["rgb"]
+
+
 def test_c_abi_frame_program_compiles_with_plain_gxx(tmp_path, miro):
     """INTEGRATION.md section 3 as a program: the whole frame through the C ABI from C++ (g++, the header, the library
     and the HIP runtime for device buffers -- no hipcc, no Python)."""
