@@ -281,11 +281,14 @@ class FrameRenderer:
             self.step(torch.cuda.current_stream(self.device), any_hit)
         return g
 
-    def render_specular(self, depth=10, stream=None):
+    def render_specular(self, depth=10, stream=None, path_tracing=False, path_seed=168, path_kinds=None):
         """Scene::traceScene with reflective / refractive materials (Scene.cpp:270-346) as wavefront bounces: every
         level traces its queue, shades it (weight x Phong::shade added to the ray's pixel), and emits the reflect /
         Fresnel / refract children of the next level by ballot compaction.  depth = TRACE_DEPTH (Miro.h:13): rays are
-        traced while depth >= 0, i.e. up to depth+1 levels.  Returns the number of rays traced per level."""
+        traced while depth >= 0, i.e. up to depth+1 levels.  Returns the number of rays traced per level.
+        path_tracing: the PATH_TRACING build of the generators (mr_gen_path_rays: lobe-sampled children, Ray.h:149-158,
+        235-239; path_kinds |= MR_PATH_DIFFUSE adds Ray::random's bounce, an extension) with stable ray ids handed down
+        the levels so that every child's random numbers are those of the oracle's recursion."""
         sc, L, W = self.scene, self.desc["light"], self.desc["wattage"]
         # this driver mixes library launches (on `stream`) with torch ops and .item() read-backs: they only order against
         # each other on torch's current stream, so `stream` must be that stream (or a torch Stream, made current here)
@@ -295,6 +298,10 @@ class FrameRenderer:
             with torch.cuda.stream(stream):
                 return self.render_specular(depth, stream)
         self.d_slots.zero_()
+        if path_kinds is None:
+            path_kinds = binding.MR_PATH_MIRROR | binding.MR_PATH_REFRACT
+        fan = 4 if path_tracing else 3                  # children per ray, at most
+        ids = None
         rays, weights, pixels, n = self.d_rays, None, None, self.n
         per_level = []
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -318,13 +325,20 @@ class FrameRenderer:
             per_level.append((n, n_shadow))
             if level == depth:
                 break
-            out_rays = torch.empty((3 * n, 8), **f32)
-            out_w = torch.empty((3 * n, 3), **f32)
-            out_pix = torch.empty(3 * n, dtype=torch.int32, device=self.device)
+            out_rays = torch.empty((fan * n, 8), **f32)
+            out_w = torch.empty((fan * n, 3), **f32)
+            out_pix = torch.empty(fan * n, dtype=torch.int32, device=self.device)
             cnt2 = torch.zeros(1, dtype=torch.int64, device=self.device)
-            sc.gen_secondary_rays(rays, hits, weights, pixels, n, out_rays, out_w, out_pix, cnt2, spp=self.spp, stream=stream)
+            if path_tracing:
+                out_ids = torch.empty(fan * n, dtype=torch.int32, device=self.device)
+                sc.gen_path_rays(rays, hits, weights, pixels, ids, n, out_rays, out_w, out_pix, out_ids, cnt2, spp=self.spp,
+                                 seed=path_seed, bounce=level, kinds=path_kinds, stream=stream)
+            else:
+                sc.gen_secondary_rays(rays, hits, weights, pixels, n, out_rays, out_w, out_pix, cnt2, spp=self.spp, stream=stream)
             n = int(cnt2.item())
             rays, weights, pixels = out_rays[:n], out_w[:n], out_pix[:n]
+            if path_tracing:
+                ids = out_ids[:n]
         self._untile(stream)
         return per_level
 

@@ -120,6 +120,9 @@ uint64_t orc_path_rays(const orc_scene *, const float *materials, const uint32_t
                        const orc_hit *hits, const float *weights, const uint32_t *pixels, const uint32_t *ids, uint64_t n,
                        uint32_t spp, uint32_t seed, uint32_t bounce, uint32_t kinds, orc_ray *out, float *out_w,
                        uint32_t *out_pix, uint32_t *out_id, uint32_t *out_kind);
+uint64_t orc_trace_scene_pt(const orc_scene *, const float *materials, const uint32_t *prim_mat, const orc_ray *rays,
+                            uint64_t n, const float light[3], const float color[3], float wattage, int depth, uint32_t seed,
+                            uint32_t kinds, float *rgb);
 void orc_miro_math(const float *x, const float *y, uint64_t n, float *out);
 uint64_t orc_trace_scene(const orc_scene *, const float *materials, const uint32_t *prim_mat, const orc_ray *rays,
                          uint64_t n, const float light[3], const float color[3], float wattage, int depth, float *rgb);

@@ -55,6 +55,18 @@ int  orc_obj_test(const orc_scene *s, uint32_t prim, const orc_ray *r, float tMi
  * N of a sphere normalised, N of a plane as set); ray may be NULL for triangle hits */
 void orc_surface(const orc_scene *s, const orc_ray *ray, const orc_hit *h, v3 *P, v3 *N, int sse_order);
 
+/* context of the restated Scene::traceScene recursions (miro_oracle_shade.c, miro_oracle_path.c) */
+typedef struct {
+    const orc_scene *s;
+    const float *mats;
+    const uint32_t *prim_mat;
+    v3 L, color;
+    float wattage;
+    uint64_t rays_traced;
+} ts_ctx;
+int  orc_ts_trace(ts_ctx *c, v3 o, v3 d, orc_hit *h, v3 *P, v3 *N);       /* Scene::trace + normalised N */
+void orc_ts_shade(ts_ctx *c, v3 d, uint32_t prim, v3 P, v3 N, float out[3]);   /* Phong::shade */
+
 int  orc_tri_test(const orc_scene *s, uint32_t prim, const orc_ray *r, float tMin, float tMax, orc_hit *out);
 void orc_sse_prepare(orc_scene *s);
 void orc_sse_free(orc_scene *s);

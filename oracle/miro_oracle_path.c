@@ -146,6 +146,93 @@ uint64_t orc_path_rays(const orc_scene *s, const float *materials, const uint32_
     return m;
 }
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Scene::traceScene (Scene.cpp:270-346) as the PATH_TRACING build runs it: the same recursion as orc_trace_scene, with the
+ * lobe-sampled generators above in place of the mirror / refraction directions.  `id` is the ray's stable id (a primary
+ * ray's index), `bounce` its recursion level; a child's id is orc_hash(id ^ 0x9e3779b9 * (kind + 1)) -- the keys the device
+ * hands down its wavefront levels.  kinds bit 2 adds the diffuse bounce (extension, weight kd).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct { ts_ctx t; uint32_t base, kinds; } pt_ctx;
+
+static int trace_scene_pt(pt_ctx *c, v3 o, v3 d, int depth, uint32_t id, uint32_t bounce, float res[3])
+{
+    const float PI = 3.1415926535897932384626433832795028841972f;
+    res[0] = res[1] = res[2] = 0.0f;
+    if (depth < 0) return 0;
+    orc_hit h; v3 P, N;
+    if (!orc_ts_trace(&c->t, o, d, &h, &P, &N)) return 1;
+    --depth;
+    const float *m = (h.prim & ORC_PLANE_BIT) ? c->t.mats + 11 * (size_t)c->t.s->plane_mat[h.prim & ~ORC_PLANE_BIT]
+                                               : c->t.mats + 11 * (size_t)c->t.prim_mat[h.prim];
+    orc_ts_shade(&c->t, d, h.prim, P, N, res);
+    const uint32_t hray = orc_hash(c->base ^ id) + bounce * 4u;
+    v3 ro, rd; float sub[3];
+    if (positive(m + 3) && (c->kinds & 1u)) {
+        reflect_pt(d, P, N, orc_hash(hray + 0u), m[9], &ro, &rd);
+        if (trace_scene_pt(c, ro, rd, depth, orc_hash(id ^ (0x9e3779b9u * 1u)), bounce + 1, sub))
+            for (int k = 0; k < 3; k++) res[k] += m[3 + k] * sub[k];
+    }
+    if (positive(m + 6) && (c->kinds & 2u)) {
+        float n1, n2; v3 nn;
+        if (v3dot(d, N) < 0) { n1 = 1.0f; n2 = m[10]; nn = N; }
+        else { n1 = m[10]; n2 = 1.0f; nn.x = -N.x; nn.y = -N.y; nn.z = -N.z; }
+        v3 md = {-d.x, -d.y, -d.z};
+        float cosTheta = v3dot(md, nn);
+        float sinTheta = mm_sinf(mm_acosf(cosTheta));
+        float q = (n1 / n2) * sinTheta, p = q * q;
+        float Rs = 1.0f;
+        if (!(p > 1.f)) {
+            float sq = sqrtf(1.f - p), fr = (n1 * cosTheta - sq) / (n1 * cosTheta + sq);
+            Rs = fr * fr;
+        }
+        if (Rs > 0.01) {
+            reflect_pt(d, P, N, orc_hash(hray + 1u), m[9], &ro, &rd);
+            if (trace_scene_pt(c, ro, rd, depth, orc_hash(id ^ (0x9e3779b9u * 2u)), bounce + 1, sub))
+                for (int k = 0; k < 3; k++) res[k] += m[6 + k] * sub[k] * Rs;
+        }
+        float dn = v3dot(d, nn);
+        float energy = (float)(1 - (pow(n1, 2) * (1 - pow(dn, 2)) / pow(n2, 2)));
+        if (energy < 0) {
+            reflect_pt(d, P, N, orc_hash(hray + 2u), m[9], &ro, &rd);
+        } else {
+            v3 t = over(v3scale(v3sub(d, v3scale(nn, dn)), n1), n2);
+            v3 d_r = v3sub(t, v3scale(nn, sqrtf(energy)));
+            float theta, phi;
+            lobe_angles(orc_hash(hray + 2u), m[9], &theta, &phi);
+            align_to_vector(d_r, P, theta, phi, &ro, &rd);
+        }
+        if (trace_scene_pt(c, ro, rd, depth, orc_hash(id ^ (0x9e3779b9u * 3u)), bounce + 1, sub))
+            for (int k = 0; k < 3; k++) res[k] += m[6 + k] * sub[k] * (1.f - Rs);
+    }
+    if (positive(m) && (c->kinds & 4u)) {
+        const uint32_t hk = orc_hash(hray + 3u);
+        float phi = mm_asinf01(sqrtf(frand_of(orc_hash(hk))));
+        float theta = 2.0f * PI * frand_of(orc_hash(hk ^ 0x68bc21ebu));
+        align_to_vector(N, P, theta, phi, &ro, &rd);
+        if (trace_scene_pt(c, ro, rd, depth, orc_hash(id ^ (0x9e3779b9u * 4u)), bounce + 1, sub))
+            for (int k = 0; k < 3; k++) res[k] += m[k] * sub[k];
+    }
+    return 1;
+}
+
+/* per-ray colours; ray i has id i; returns the number of Scene::trace calls made */
+uint64_t orc_trace_scene_pt(const orc_scene *s, const float *materials, const uint32_t *prim_mat, const orc_ray *rays,
+                            uint64_t n, const float light[3], const float color[3], float wattage, int depth, uint32_t seed,
+                            uint32_t kinds, float *rgb)
+{
+    pt_ctx c;
+    c.t.s = s; c.t.mats = materials; c.t.prim_mat = prim_mat;
+    c.t.L.x = light[0]; c.t.L.y = light[1]; c.t.L.z = light[2];
+    c.t.color.x = color[0]; c.t.color.y = color[1]; c.t.color.z = color[2];
+    c.t.wattage = wattage; c.t.rays_traced = 0;
+    c.base = orc_hash(seed); c.kinds = kinds;
+    for (uint64_t i = 0; i < n; i++) {
+        v3 o = {rays[i].ox, rays[i].oy, rays[i].oz}, d = {rays[i].dx, rays[i].dy, rays[i].dz};
+        trace_scene_pt(&c, o, d, depth, (uint32_t)i, 0u, rgb + 3 * i);
+    }
+    return c.t.rays_traced;
+}
+
 /* miro_math.h's float functions, for tests/test_miro_math.py: out[5*i..] = sin, cos, asin01, acos01, pow01(x, y) */
 void orc_miro_math(const float *x, const float *y, uint64_t n, float *out)
 {

@@ -74,14 +74,7 @@ void orc_tonemap(const float *rgb, uint64_t n_values, unsigned char *out)
  * materials: 11 floats each = diffuse[3], specular[3], transmission[3], shininess, refract_index, already
  * clamped as the Phong constructor does (Phong.cpp:12-33).  prim_mat: material id per triangle.
  * ------------------------------------------------------------------------------------------------------------ */
-typedef struct {
-    const orc_scene *s;
-    const float *mats;
-    const uint32_t *prim_mat;
-    v3 L, color;
-    float wattage;
-    uint64_t rays_traced;
-} ts_ctx;
+/* ts_ctx: miro_oracle_internal.h */
 
 static inline const float *mat_of(const ts_ctx *c, uint32_t prim)
 {
@@ -228,3 +221,7 @@ uint64_t orc_trace_scene(const orc_scene *s, const float *materials, const uint3
     }
     return c.rays_traced;
 }
+
+/* the two pieces of Scene::traceScene that the PATH_TRACING recursion of miro_oracle_path.c shares with the one above */
+int orc_ts_trace(ts_ctx *c, v3 o, v3 d, orc_hit *h, v3 *P, v3 *N) { return scene_trace(c, o, d, 0.0f, 1e12f, h, P, N); }
+void orc_ts_shade(ts_ctx *c, v3 d, uint32_t prim, v3 P, v3 N, float out[3]) { phong_shade(c, d, prim, P, N, out); }

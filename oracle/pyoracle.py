@@ -76,6 +76,8 @@ def lib():
                                     C.c_uint32, vp, f32p, u32p, u32p, u32p]
         L.orc_path_rays.restype = C.c_uint64
         L.orc_miro_math.argtypes = [f32p, f32p, C.c_uint64, f32p]
+        L.orc_trace_scene_pt.argtypes = [vp, f32p, u32p, vp, C.c_uint64, f32p, f32p, C.c_float, C.c_int, C.c_uint32, C.c_uint32, f32p]
+        L.orc_trace_scene_pt.restype = C.c_uint64
         L.orc_pmap_new.argtypes = [C.c_int]
         L.orc_pmap_new.restype = vp
         L.orc_pmap_free.argtypes = [vp]
@@ -243,6 +245,17 @@ class Scene:
         l, c = (np.ascontiguousarray(x, dtype=np.float32) for x in (light, color))
         calls = self.L.orc_trace_scene(self.h, _f32p(m), _u32p(pm), rays.ctypes.data, len(rays), _f32p(l), _f32p(c),
                                        wattage, depth, _f32p(rgb))
+        return rgb, calls
+
+    def trace_scene_pt(self, materials, prim_mat, rays, light, wattage, depth=10, seed=168, kinds=3, color=(1, 1, 1)):
+        """Scene::traceScene as the PATH_TRACING build runs it (lobe-sampled reflect / refract; kinds & 4: + diffuse bounce)."""
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        m = np.ascontiguousarray(materials, dtype=np.float32).reshape(-1, 11)
+        pm = np.ascontiguousarray(prim_mat, dtype=np.uint32)
+        rgb = np.empty((len(rays), 3), np.float32)
+        l, c = (np.ascontiguousarray(x, dtype=np.float32) for x in (light, color))
+        calls = self.L.orc_trace_scene_pt(self.h, _f32p(m), _u32p(pm), rays.ctypes.data, len(rays), _f32p(l), _f32p(c),
+                                          wattage, depth, seed, kinds, _f32p(rgb))
         return rgb, calls
 
     def path_rays(self, materials, prim_mat, rays, hits, weights=None, pixels=None, ids=None, spp=1, seed=168, bounce=0, kinds=7):

@@ -76,6 +76,37 @@ def test_specular_frame_matches_oracle(oracle, miro):
     assert scale > 0
 
 
+@pytest.mark.parametrize("kinds,depth", [(3, 4), (7, 2)])
+def test_path_traced_frame_matches_oracle(oracle, miro, kinds, depth):
+    """Scene::traceScene as the PATH_TRACING build runs it -- glossy mirror (finite shininess) and rough glass, every child
+    drawn from its lobe with the counter-based generator; kinds = 7 adds the diffuse bounce of Ray::random (extension).
+    Same ray totals per level as the oracle's recursion makes Scene::trace calls, pixels within the tolerance of the
+    mirror-direction test (float atomics reorder the per-pixel sums; the rays themselves are bit-equal, test_path_rays.py)."""
+    import torch
+    a, b, _, prim_mat = build_both(oracle, miro)
+    mats = [phong((0.4, 0.4, 0.5), ks=(0.6, 0.6, 0.5), shininess=30.0),
+            phong((1, 1, 1), kt=(0.9, 0.95, 1.0), shininess=200.0, index=1.5),
+            phong((0.8, 0.8, 0.8))]
+    b.set_materials(mats, prim_mat)
+    mats11 = clamp_like_phong_ctor(mats)
+    d = scenes.SCENES["teapot"]
+    W, H, spp = 64, 48, 2
+    fr = mframe.FrameRenderer(b, d, W, H, spp=spp)
+    fr.generate()
+    levels = fr.render_specular(depth=depth, path_tracing=True, path_seed=99, path_kinds=kinds)
+    torch.cuda.synchronize()
+    got = fr.d_rgb.cpu().numpy()
+    rays = oracle.eye_rays(camera_of(oracle, "teapot"), W, H, spp=spp, jitter=True, seed=168)
+    per_ray, calls = a.trace_scene_pt(mats11, prim_mat, rays, d["light"], d["wattage"], depth=depth, seed=99, kinds=kinds)
+    want = per_ray.reshape(H * W, spp, 3).astype(np.float64).mean(axis=1)
+    # Scene::trace calls of the recursion = rays traced by the wavefront levels (primary / bounce rays + their shadow rays)
+    assert calls == sum(n for n, _ in levels) + sum(s for _, s in levels)
+    assert len(levels) >= 2 and levels[1][0] > 0
+    scale = max(1e-6, float(np.abs(want).max()))
+    err = np.abs(got - want)
+    assert (err.max(axis=1) <= 2e-4 * scale).mean() > 0.995 and np.median(err) <= 1e-6 * scale
+
+
 def test_default_material_equals_direct_shade(oracle, miro):
     """Without mr_scene_set_materials every triangle is the white Lambert: the general accumulate path must give
     the picture of the deterministic single-bounce path (up to float-atomic ordering -> identical here, one add per
