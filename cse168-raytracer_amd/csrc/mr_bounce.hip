@@ -133,6 +133,27 @@ struct BounceArgs {
     unsigned long long *count;
 };
 
+// Output slots for a workgroup's children: every wave brings its count, ONE atomicAdd per workgroup reserves the range (a
+// single counter word drains ~88 atomics per microsecond -- one atomic per wave made the generators atomic-bound: 2.7 ms for
+// the 16.8 M rays of a bunny frame against 0.7 ms for tracing their children).  Called by all threads of the workgroup.
+__device__ __forceinline__ unsigned long long workgroup_reserve(unsigned wave_total, unsigned long long *count) {
+    __shared__ unsigned s_tot[kBlock / 64];
+    __shared__ unsigned long long s_base;
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) s_tot[wave] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned tot = 0;
+        for (int w = 0; w < kBlock / 64; w++) tot += s_tot[w];
+        s_base = tot ? atomicAdd(count, (unsigned long long)tot) : 0ull;
+    }
+    __syncthreads();
+    unsigned long long base = s_base;
+    for (int w = 0; w < wave; w++) base += s_tot[w];
+    __syncthreads();                                      // s_tot / s_base are reused by the next round
+    return base;
+}
+
 __device__ __forceinline__ void reflect_dir(const float d[3], const float N[3], float r[3]) {       // Ray.h:160-162
     const float two = 2 * ((N[0] * d[0] + N[1] * d[1]) + N[2] * d[2]);
     r[0] = d[0] - two * N[0]; r[1] = d[1] - two * N[1]; r[2] = d[2] - two * N[2];
@@ -143,7 +164,7 @@ __device__ __forceinline__ void reflect_dir(const float d[3], const float N[3], 
 __global__ __launch_bounds__(kBlock) void secondary_rays_kernel(BounceArgs a) {
     const int lane = threadIdx.x & 63;
     const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
-    const unsigned long long n_round = (a.n + 63ull) & ~63ull;
+    const unsigned long long n_round = (a.n + (unsigned long long)kBlock - 1ull) / kBlock * kBlock;     // whole workgroups
     for (unsigned long long k = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; k < n_round; k += stride) {
         // up to three children: 0 = mirror reflection, 1 = Fresnel reflection, 2 = refraction (or its total internal reflection)
         bool emit[3] = {false, false, false};
@@ -207,13 +228,10 @@ __global__ __launch_bounds__(kBlock) void secondary_rays_kernel(BounceArgs a) {
                 }
             }
         }
-        // wave64 compaction: one ballot per child kind, one atomic per wave for the three together
+        // wave64 compaction: one ballot per child kind; the workgroup's waves share one atomic
         const unsigned long long m0 = __ballot(emit[0]), m1 = __ballot(emit[1]), m2 = __ballot(emit[2]);
         const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2);
-        if (c0 + c1 + c2 == 0) continue;
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(a.count, (unsigned long long)(c0 + c1 + c2));
-        base = __shfl(base, 0, 64);
+        const unsigned long long base = workgroup_reserve((unsigned)(c0 + c1 + c2), a.count);
         const unsigned long long lt = (1ull << lane) - 1ull;
         const unsigned long long slot[3] = {base + __popcll(m0 & lt), base + c0 + __popcll(m1 & lt), base + c0 + c1 + __popcll(m2 & lt)};
         for (int j = 0; j < 3; j++) {
@@ -281,7 +299,7 @@ __device__ __forceinline__ void align_to_vector(const float v[3], const float P[
 __global__ __launch_bounds__(kBlock) void path_rays_kernel(PathArgs a) {
     const int lane = threadIdx.x & 63;
     const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
-    const unsigned long long n_round = (a.n + 63ull) & ~63ull;
+    const unsigned long long n_round = (a.n + (unsigned long long)kBlock - 1ull) / kBlock * kBlock;     // whole workgroups
     for (unsigned long long k = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; k < n_round; k += stride) {
         bool emit[4] = {false, false, false, false};
         float dir[4][3], org[4][3], wgt[4][3];
@@ -366,14 +384,11 @@ __global__ __launch_bounds__(kBlock) void path_rays_kernel(PathArgs a) {
                 }
             }
         }
-        // wave64 compaction: one ballot per child kind, one atomic per wave for all of them
+        // wave64 compaction: one ballot per child kind; the workgroup's waves share one atomic
         unsigned long long mk[4];
         int cn[4], tot = 0;
         for (int j = 0; j < 4; j++) { mk[j] = __ballot(emit[j]); cn[j] = __popcll(mk[j]); tot += cn[j]; }
-        if (tot == 0) continue;
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(a.count, (unsigned long long)tot);
-        base = __shfl(base, 0, 64);
+        const unsigned long long base = workgroup_reserve((unsigned)tot, a.count);
         const unsigned long long lt = (1ull << lane) - 1ull;
         unsigned long long before = base;
         for (int j = 0; j < 4; j++) {
