@@ -227,3 +227,48 @@ def test_random_cameras_bit_exact(oracle, miro, seed):
         assert n == len(want)
         got = d[:n].cpu().numpy()
         assert _same_bits_or_nan(got, want.view(np.float32).reshape(-1, 8)), (eye, look, up, fov, W, H, spp, jitter, sd, y0, y1)
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_scene_fused_frame_equals_batched_pipeline(miro, seed):
+    """mr_render_direct (one launch, rays in registers) against the batched pipeline on the fuzz scenes -- grid soups with
+    exact ties, spheres of radius 0, planes, leaf sizes 1-8 -- under random cameras, frame sizes, sample counts, sample
+    orders, arithmetic modes and band splits: primary records, the shadow record of every sample, ray counts and the float
+    framebuffer must be the same bits (NaN pixels, which zero-length normals produce, compared by position)."""
+    import torch
+    from miro_amd import frame as mframe
+    rng = np.random.default_rng(BASE + seed + 7919)
+    steps, leaf, extent = make_scene(rng)
+    sc = replay(miro.Scene(), steps, leaf)
+    for _ in range(3):
+        eye = ((rng.random(3) - 0.5) * 4 * extent).astype(np.float32)
+        desc = dict(eye=[float(x) for x in eye], lookat=[float(x) for x in (rng.random(3) - 0.5) * extent], up=[0.0, 1.0, 0.0],
+                    fov=float(rng.choice([20.0, 45.0, 90.0, 140.0])), light=[float(x) for x in (rng.random(3) - 0.5) * 3 * extent],
+                    wattage=float(rng.choice([10.0, 700.0])))
+        W, H = int(rng.integers(1, 90)), int(rng.integers(1, 70))
+        spp = int(rng.choice([1, 2, 4, 16, 64]))
+        tiled = bool(rng.random() < 0.6)
+        flags = int(rng.choice([0, miro.MR_MATH_PRODUCT, miro.MR_TRACE_INCOHERENT]))
+        ref = mframe.FrameRenderer(sc, desc, W, H, spp=spp, flags=flags, tiled=tiled)
+        ref.generate()
+        ref.step()
+        fu = mframe.FusedFrame(sc, desc, W, H, spp=spp, flags=flags, tiled=tiled, keep_hits=True)
+        fu.step()
+        torch.cuda.synchronize()
+        n_p, n_s = ref.ray_counts()
+        assert fu.ray_counts() == (n_p, n_s)
+        assert torch.equal(fu.d_hits.view(torch.int32), ref.d_hits.view(torch.int32))
+        src = ref.d_src[:n_s].to(torch.int64)
+        assert torch.equal(fu.d_shadow_hits[src].view(torch.int32), ref.d_shadow_hits[:n_s].view(torch.int32))
+        assert _same_bits_or_nan(fu.d_rgb.cpu().numpy(), ref.d_rgb.cpu().numpy())
+        # the same frame as two ranks' interleaved bands
+        band = int(rng.integers(1, 9))
+        full = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        for r in range(2):
+            part = mframe.FusedFrame(sc, desc, W, H, spp=spp, flags=flags, tiled=tiled, band=band, rank=r, world=2)
+            part.step()
+            rows = torch.from_numpy(mframe.rows_of(mframe.band_rows(H, band, r, 2))).to("cuda")
+            if len(rows):
+                full[rows] = part.d_rgb.view(len(rows), W, 3)
+        torch.cuda.synchronize()
+        assert _same_bits_or_nan(full.view(-1, 3).cpu().numpy(), ref.d_rgb.cpu().numpy())
