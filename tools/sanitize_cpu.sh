@@ -17,8 +17,8 @@ restore() {
 trap restore EXIT
 
 echo "== oracle under ASan + UBSan"
-for f in miro_oracle miro_oracle_shade miro_oracle_photon; do
-    gcc -std=c99 -O1 -g -fPIC -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -I"$ROOT/oracle" \
+for f in miro_oracle miro_oracle_shade miro_oracle_photon miro_oracle_path; do
+    gcc -std=c99 -O1 -g -fPIC -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -I"$ROOT/oracle" -I"$ROOT/include" \
         -c "$ROOT/oracle/$f.c" -o "$T/$f.o"
 done
 gcc -std=gnu11 -O1 -g -fPIC -msse4.1 -fopenmp -ffp-contract=off -fsanitize=address,undefined -I"$ROOT/oracle" \
@@ -28,7 +28,7 @@ cp "$ROOT/oracle/libmiro_oracle.so" "$T/orig_oracle.so"
 cp "$T/libmiro_oracle.so" "$ROOT/oracle/libmiro_oracle.so"
 (cd "$ROOT" && LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
     ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
-    python -m pytest tests/test_oracle_kat.py tests/test_objects.py tests/test_photon.py -x -q -m "not gpu" -p no:cacheprovider)
+    python -m pytest tests/test_oracle_kat.py tests/test_objects.py tests/test_photon.py tests/test_path_rays.py -x -q -m "not gpu" -p no:cacheprovider)
 cp "$T/orig_oracle.so" "$ROOT/oracle/libmiro_oracle.so"
 
 echo "== product host code under ASan"
