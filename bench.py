@@ -188,8 +188,8 @@ def committed_pmc(workload):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)      # 50 x 19 ms: a timed region of about a second
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default="sponza")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
