@@ -5,6 +5,8 @@
 //   eye_rays_kernel     Camera::eyeRay (Camera.cpp:104-161)
 //   shadow_rays_kernel  Phong::shade shadow ray (Phong.cpp:80-97) + wave64 ballot compaction
 //   hit_attrs_kernel    HitInfo::P / ::N (Triangle.cpp:160,162)
+// The traversal itself (slab tests, triangle / sphere tests, LDS stack, control-flow modes) is mr_traverse.h, shared with
+// the fused frame kernel of mr_frame.hip; this file holds the batched kernels around it and their launch logic.
 //
 // Compiled with -ffp-contract=off: in the default ("exact") mode every fp32 operation below is one
 // individually rounded IEEE op in the reference's order, so t / beta / gamma are bit-identical to the
