@@ -233,7 +233,7 @@ uint64_t orc_trace_scene_pt(const orc_scene *s, const float *materials, const ui
     return c.t.rays_traced;
 }
 
-/* miro_math.h's float functions, for tests/test_miro_math.py: out[5*i..] = sin, cos, asin01, acos01, pow01(x, y) */
+/* miro_math.h's float functions, for tests/test_path_rays.py: out[5*i..] = sin, cos, asin01, acos01, pow01(x, y) */
 void orc_miro_math(const float *x, const float *y, uint64_t n, float *out)
 {
     for (uint64_t i = 0; i < n; i++) {
