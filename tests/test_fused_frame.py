@@ -135,11 +135,13 @@ def test_fused_frame_rejects_what_it_cannot_do(miro):
         sc.render_direct(cam, 16, 16, rgb, (0, 1, 0), 100.0, flags=binding.MR_COUNT_STATS)
 
 
-def test_fused_frame_full_size_properties(miro):
-    """BASELINE config 4 at full size (1920x1080, 64 spp is 132.7 M samples: 16 spp here keeps the hit buffers at 1 GB):
-    size-independent checks -- idempotence (two steps, same bytes), ray-count conservation (closed scene: one shadow ray
-    per primary ray), and equality with the batched pipeline's picture."""
-    name, W, H, spp = "sponza", 1920, 1080, 16
+@pytest.mark.parametrize("spp", [16, 64])
+def test_fused_frame_full_size_properties(miro, spp):
+    """BASELINE config 4 at full size (1920x1080; 64 spp = 132.7 M samples, the bench frame; the batched pipeline it is
+    compared with keeps 13.3 GB of rays and hits resident, the fused one 25 MB): size-independent checks -- idempotence
+    (two steps, same bytes), ray-count conservation (closed scene: one shadow ray per primary ray), and equality with the
+    batched pipeline's picture."""
+    name, W, H = "sponza", 1920, 1080
     sc = product_scene(miro, name)
     fu = mframe.FusedFrame(sc, name, W, H, spp=spp)
     fu.step()
