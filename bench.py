@@ -256,7 +256,7 @@ def main():
 
     # multi-GPU: two send buffers, used by alternate frames, so that frame k's gather (asynchronous, RCCL's own stream)
     # overlaps frame k+1's launch -- the kernel of frame k+1 writes the other buffer
-    gathers = [mframe.FrameGather(H, W, a.band, rank, world, dev) for _ in range(2)] if world > 1 else None
+    gathers = [mframe.FrameGather(H, W, a.band, rank, world, dev, scene=scene) for _ in range(2)] if world > 1 else None
     if fused:
         frs = [mframe.FusedFrame(scene, desc, W, H, spp=spp, band=a.band, rank=rank, world=world, jitter=spp > 1, seed=168,
                                  flags=flags, rgb=g.local if g is not None and len(bands) else None, tiled=tiled,

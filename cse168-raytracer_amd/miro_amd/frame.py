@@ -39,10 +39,13 @@ class FrameGather:
     before it shades the next frame, so frame k's gather overlaps frame k+1's trace launches."""
 
     def __init__(self, H, W, band, rank, world, device, dtype=torch.float32, group=None, dst=0, always_collective=False,
-                 channels=3):
+                 channels=3, scene=None):
         """always_collective: go through torch.distributed even when world == 1 (exercises the RCCL call on one GPU).
         channels: values per pixel -- 3 for the float framebuffer; 4 * spp gathers the frame's mr_hit records instead
         (the hit-buffer parity mode of SURVEY.md section 8e: 16 bytes per ray, viewed as float32)."""
+        # scene: a built miro_amd.Scene on `device`; with it rank `dst` de-interleaves with the library's own kernel
+        # (mr_deinterleave_bands, one launch on the current stream) instead of a torch index_select + index_copy_ pair
+        self.scene = scene if dtype == torch.float32 else None
         self.channels = C = channels
         self.H, self.W, self.band, self.rank, self.world, self.group, self.dst = H, W, band, rank, world, group, dst
         self.local_only = world == 1 and not always_collective
@@ -95,6 +98,10 @@ class FrameGather:
         self.pending = False
         if self.rank != self.dst:
             return None
+        if self.scene is not None and self.recv.is_cuda:
+            self.scene.deinterleave_bands(self.recv, self.full, self.W, self.H, self.band, self.world, max(self.max_rows, 1),
+                                          self.channels, stream=torch.cuda.current_stream(self.recv.device))
+            return self.full
         rows = self.recv.reshape(-1, self.W * self.channels).index_select(0, self.src_rows)
         self.full.view(self.H, self.W * self.channels).index_copy_(0, self.dest_rows, rows)
         return self.full

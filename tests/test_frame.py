@@ -198,7 +198,7 @@ def test_tile_sharding_is_invisible_in_the_result(miro, world):
 
 
 @gpu
-def test_frame_gather_through_rccl_single_rank():
+def test_frame_gather_through_rccl_single_rank(miro):
     """The collective exactly as bench.py issues it at N>1 -- asynchronous dist.gather on the "nccl" (= RCCL) backend
     into views of one receive buffer, stream-level wait, de-interleave on the device -- exercised with a one-rank
     process group, which is all a one-GPU box can hold."""
@@ -210,15 +210,17 @@ def test_frame_gather_through_rccl_single_rank():
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         H, W, band = 37, 5, 8
-        g = mframe.FrameGather(H, W, band, 0, 1, dev, always_collective=True)
-        base = (torch.arange(H * W, dtype=torch.float32, device=dev).reshape(-1, 1) * 4 + torch.arange(3, dtype=torch.float32, device=dev))
-        for k in range(3):
-            g.wait()
-            g.local.copy_(base + 1000.0 * k)
-            g.start()
-        full = g.wait()
-        torch.cuda.synchronize()
-        assert torch.equal(full.reshape(-1, 3), base + 2000.0)
+        # de-interleave by torch index ops (scene=None) and by the library's mr_deinterleave_bands (what bench.py passes)
+        for scene in (None, product_scene(miro, "teapot")):
+            g = mframe.FrameGather(H, W, band, 0, 1, dev, always_collective=True, scene=scene)
+            base = (torch.arange(H * W, dtype=torch.float32, device=dev).reshape(-1, 1) * 4 + torch.arange(3, dtype=torch.float32, device=dev))
+            for k in range(3):
+                g.wait()
+                g.local.copy_(base + 1000.0 * k)
+                g.start()
+            full = g.wait()
+            torch.cuda.synchronize()
+            assert torch.equal(full.reshape(-1, 3), base + 2000.0)
     finally:
         dist.destroy_process_group()
 
