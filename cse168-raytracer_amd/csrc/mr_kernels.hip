@@ -301,7 +301,11 @@ inline int trace_grid_cap() {
 
 template <bool EXACT, bool ANY, bool STATS, int VAR>
 mr_status launch_trace_t(const TraceParams &p, hipStream_t stream) {
-    const size_t lds = (size_t)p.stack_depth * kTraceBlock * sizeof(int);
+    size_t lds = (size_t)p.stack_depth * kTraceBlock * sizeof(int);
+#ifdef MIRO_DEV
+    // occupancy experiments: MIRO_LDS_PAD bytes of unused LDS per workgroup (fewer workgroups per CU)
+    { static const size_t pad = getenv("MIRO_LDS_PAD") ? (size_t)atoi(getenv("MIRO_LDS_PAD")) : 0; lds += pad; }
+#endif
     if (lds > 160 * 1024) return fail(MR_ERR_INVALID, "traversal stack of depth %d does not fit in LDS", p.stack_depth);
     if (lds > 64 * 1024)
         MR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&trace_kernel<EXACT, ANY, STATS, VAR>),
