@@ -46,6 +46,19 @@ def test_bench_prints_one_contract_line():
 
 
 @pytest.mark.gpu
+def test_bench_batched_pipeline_still_runs():
+    """`--batched`: the round-1 step (five kernels over resident rays) stays available for comparison; its line carries the
+    per-launch times of both trace launches and no VALU fraction (the committed counters belong to the fused kernel)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batched",
+                        "--width", "320", "--height", "184", "--spp", "4", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["value"] > 0 and j["config"]["step"].startswith("batched")
+    assert set(j["roofline"]["avg_launch_ms"]) == {"primary", "shadow"} and j["roofline"]["frac"] is None
+    assert j["config"]["resident_bytes_per_gpu"] > 320 * 184 * 4 * 100
+
+
+@pytest.mark.gpu
 def test_bench_two_ranks_rehearsal():
     """The N > 1 flow of bench.py -- rendezvous, interleaved row bands, per-rank frames, the pipelined framebuffer gather,
     max-over-ranks timing, one line from rank 0 -- with two ranks sharing this box's GPU.  The collectives run over gloo
