@@ -735,6 +735,31 @@ mr_status mr_gen_path_rays(mr_scene *s, const mr_ray *d_rays, const mr_hit *d_hi
                             static_cast<hipStream_t>(stream));
 }
 
+mr_status mr_trace_level(mr_scene *s, const mr_level_desc *level, const mr_ray *d_rays, const float *d_weights,
+                         const uint32_t *d_pixels, const uint32_t *d_ids, uint64_t n, float *d_rgb, mr_ray *d_out_rays,
+                         float *d_out_weights, uint32_t *d_out_pixels, uint32_t *d_out_ids, uint64_t *d_out_count,
+                         uint64_t *d_counts, void *stream) {
+    mr_status st = require_device(s);
+    if (st != MR_OK) return st;
+    if (!level || !d_rays || !d_rgb) return fail(MR_ERR_INVALID, "NULL argument");
+    if (level->children > MR_LEVEL_PATH) return fail(MR_ERR_INVALID, "mr_trace_level: children must be MR_LEVEL_LAST, _SPECULAR or _PATH");
+    if (level->children != MR_LEVEL_LAST && (!d_out_rays || !d_out_weights || !d_out_pixels || !d_out_count))
+        return fail(MR_ERR_INVALID, "mr_trace_level: a level with children needs the output queue");
+    if (level->spp == 0) return fail(MR_ERR_INVALID, "spp is 0");
+    if (n > 0xFFFFFFFFull) return fail(MR_ERR_INVALID, "mr_trace_level: at most 2^32 - 1 rays per call");
+    if (level->children == MR_LEVEL_PATH && (level->path_kinds == 0 || (level->path_kinds & ~7u)))
+        return fail(MR_ERR_INVALID, "path_kinds must be a combination of MR_PATH_MIRROR | MR_PATH_REFRACT | MR_PATH_DIFFUSE");
+    if (level->flags & ~(uint32_t)(MR_MATH_PRODUCT | MR_TRACE_INCOHERENT))
+        return fail(MR_ERR_INVALID, "mr_trace_level: flags may hold MR_MATH_PRODUCT, MR_TRACE_INCOHERENT only");
+    if ((reinterpret_cast<uintptr_t>(d_rays) & 15) || (reinterpret_cast<uintptr_t>(d_out_rays) & 15) ||
+        (reinterpret_cast<uintptr_t>(d_out_count) & 7) || (reinterpret_cast<uintptr_t>(d_counts) & 7))
+        return fail(MR_ERR_INVALID, "ray queues must be 16-byte aligned, counters 8-byte aligned");
+    MR_HIP_CHECK(hipSetDevice(s->device));
+    return launch_level(s->dev, *level, d_rays, d_weights, d_pixels, d_ids, n, d_rgb, d_out_rays, d_out_weights, d_out_pixels,
+                        d_out_ids, reinterpret_cast<unsigned long long *>(d_out_count),
+                        reinterpret_cast<unsigned long long *>(d_counts), static_cast<hipStream_t>(stream));
+}
+
 mr_status mr_tonemap(mr_scene *s, const float *d_rgb, uint64_t n_values, uint8_t *d_out, void *stream) {
     if (!s || !d_rgb || !d_out) return fail(MR_ERR_INVALID, "NULL argument");
     MR_HIP_CHECK(hipSetDevice(s->device));

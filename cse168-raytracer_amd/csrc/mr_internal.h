@@ -169,6 +169,11 @@ mr_status launch_path_rays(const DeviceScene &ds, const mr_ray *d_rays, const mr
                            uint32_t bounce, uint32_t kinds, mr_ray *d_out_rays, float *d_out_weights, uint32_t *d_out_pixels,
                            uint32_t *d_out_ids, unsigned long long *d_count, hipStream_t stream);
 
+mr_status launch_level(const DeviceScene &ds, const mr_level_desc &ld, const mr_ray *d_rays, const float *d_weights,
+                       const uint32_t *d_pixels, const uint32_t *d_ids, unsigned long long n, float *d_rgb, mr_ray *d_out_rays,
+                       float *d_out_weights, uint32_t *d_out_pixels, uint32_t *d_out_ids, unsigned long long *d_out_count,
+                       unsigned long long *d_counts, hipStream_t stream);
+
 // photon map on the device: three float4 planes in kd-tree heap order, 1-based (children of i: 2i, 2i+1)
 struct PhotonMapDev {
     float4 *posplane = nullptr;   // (x, y, z, split axis as int bits)

@@ -25,6 +25,7 @@ MR_MATH_PRODUCT = 1 << 6
 MR_TRACE_INCOHERENT = 1 << 7
 
 MR_PATH_MIRROR, MR_PATH_REFRACT, MR_PATH_DIFFUSE = 1, 2, 4
+MR_LEVEL_LAST, MR_LEVEL_SPECULAR, MR_LEVEL_PATH = 0, 1, 2
 
 MR_OK, MR_ERR_INVALID, MR_ERR_IO, MR_ERR_NOMEM, MR_ERR_HIP, MR_ERR_STATE = 0, -1, -2, -3, -4, -5
 
@@ -34,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "mr_scene_add_sphere", "mr_scene_add_plane",
     "mr_bvh_build", "mr_scene_get_info", "mr_scene_get_mesh", "mr_scene_export_tree",
     "mr_trace", "mr_host_alloc", "mr_host_free", "mr_trace_indirect", "mr_trace_get_stats", "mr_gen_eye_rays", "mr_gen_eye_rays_tiled", "mr_tile_pixel_map", "mr_untile_pixels", "mr_gen_shadow_rays", "mr_hit_attrs",
-    "mr_shade_direct", "mr_render_direct", "mr_band_locate", "mr_band_rows_of", "mr_deinterleave_bands", "mr_gen_path_rays", "mr_tonemap",
+    "mr_shade_direct", "mr_render_direct", "mr_band_locate", "mr_band_rows_of", "mr_deinterleave_bands", "mr_gen_path_rays", "mr_trace_level", "mr_tonemap",
     "mr_scene_set_materials", "mr_shade_accumulate", "mr_gen_secondary_rays",
     "mr_photon_map_create", "mr_photon_map_destroy", "mr_photon_map_store", "mr_photon_map_scale",
     "mr_photon_map_balance", "mr_photon_map_count", "mr_photon_map_export", "mr_irradiance_estimate",
@@ -83,6 +84,12 @@ class FrameDesc(C.Structure):
                 ("band_rows", C.c_uint32), ("band_rank", C.c_uint32), ("band_world", C.c_uint32),
                 ("spp", C.c_uint32), ("jitter", C.c_uint32), ("seed", C.c_uint32), ("tiled", C.c_uint32),
                 ("flags", C.c_uint32), ("light", Light), ("diffuse", C.c_float * 3), ("reserved", C.c_uint32 * 4)]
+
+
+class LevelDesc(C.Structure):
+    """mr_level_desc (miro_hip.h): one level of traceScene's recursion for mr_trace_level"""
+    _fields_ = [("light", Light), ("spp", C.c_uint32), ("flags", C.c_uint32), ("children", C.c_uint32),
+                ("path_kinds", C.c_uint32), ("seed", C.c_uint32), ("bounce", C.c_uint32), ("reserved", C.c_uint32 * 4)]
 
 
 class Material(C.Structure):
@@ -155,6 +162,7 @@ def load_library(path=None):
     L.mr_shade_accumulate.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, C.POINTER(Light), C.c_uint32, vp, vp]
     L.mr_gen_secondary_rays.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp, vp]
     L.mr_gen_path_rays.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp]
+    L.mr_trace_level.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp, vp]
     L.mr_final_gather.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_float, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.mr_photon_map_create.argtypes = [C.c_int32, C.c_uint32, C.POINTER(vp)]
     L.mr_photon_map_destroy.argtypes = [vp]
@@ -410,6 +418,22 @@ class Scene:
         _check(self.L.mr_gen_path_rays(self.h, d_rays.data_ptr(), d_hits.data_ptr(), ptr(d_weights), ptr(d_pixels), ptr(d_ids),
                                        n, spp, seed, bounce, kinds, d_out_rays.data_ptr(), d_out_weights.data_ptr(),
                                        d_out_pixels.data_ptr(), ptr(d_out_ids), d_count.data_ptr(), _stream_ptr(stream)))
+
+    def trace_level(self, d_rays, d_weights, d_pixels, d_ids, n, d_rgb, light_pos, wattage, children=MR_LEVEL_LAST, d_out_rays=None,
+                    d_out_weights=None, d_out_pixels=None, d_out_ids=None, d_out_count=None, d_counts=None, spp=1, flags=0,
+                    seed=168, bounce=0, kinds=MR_PATH_MIRROR | MR_PATH_REFRACT, color=(1.0, 1.0, 1.0), stream=None):
+        """mr_trace_level: trace -> shadow ray -> trace -> Phong::shade x weight -> pixel, and the next level's queue, in
+        one launch (Scene.cpp:270-346)"""
+        def ptr(t):
+            return t.data_ptr() if t is not None else None
+        ld = LevelDesc()
+        ld.light.position[:] = light_pos
+        ld.light.color[:] = color
+        ld.light.wattage = wattage
+        ld.spp, ld.flags, ld.children, ld.path_kinds, ld.seed, ld.bounce = spp, flags, children, kinds, seed, bounce
+        _check(self.L.mr_trace_level(self.h, C.byref(ld), d_rays.data_ptr(), ptr(d_weights), ptr(d_pixels), ptr(d_ids), n,
+                                     d_rgb.data_ptr(), ptr(d_out_rays), ptr(d_out_weights), ptr(d_out_pixels), ptr(d_out_ids),
+                                     ptr(d_out_count), ptr(d_counts), _stream_ptr(stream)))
 
     def deinterleave_bands(self, d_recv, d_full, W, H, band_rows, world, shard_rows, floats_per_pixel=3, stream=None):
         _check(self.L.mr_deinterleave_bands(self.h, d_recv.data_ptr(), d_full.data_ptr(), W, H, band_rows, world, shard_rows,

@@ -288,14 +288,16 @@ class FrameRenderer:
             self.step(torch.cuda.current_stream(self.device), any_hit)
         return g
 
-    def render_specular(self, depth=10, stream=None, path_tracing=False, path_seed=168, path_kinds=None):
+    def render_specular(self, depth=10, stream=None, path_tracing=False, path_seed=168, path_kinds=None, fused=False):
         """Scene::traceScene with reflective / refractive materials (Scene.cpp:270-346) as wavefront bounces: every
         level traces its queue, shades it (weight x Phong::shade added to the ray's pixel), and emits the reflect /
         Fresnel / refract children of the next level by ballot compaction.  depth = TRACE_DEPTH (Miro.h:13): rays are
         traced while depth >= 0, i.e. up to depth+1 levels.  Returns the number of rays traced per level.
         path_tracing: the PATH_TRACING build of the generators (mr_gen_path_rays: lobe-sampled children, Ray.h:149-158,
         235-239; path_kinds |= MR_PATH_DIFFUSE adds Ray::random's bounce, an extension) with stable ray ids handed down
-        the levels so that every child's random numbers are those of the oracle's recursion."""
+        the levels so that every child's random numbers are those of the oracle's recursion.
+        fused: every level is ONE launch of mr_trace_level (trace, shadow ray, trace, shade, children) instead of the seven
+        of the batched calls -- the same rays and children; no hit or shadow-ray buffer exists."""
         sc, L, W = self.scene, self.desc["light"], self.desc["wattage"]
         # this driver mixes library launches (on `stream`) with torch ops and .item() read-backs: they only order against
         # each other on torch's current stream, so `stream` must be that stream (or a torch Stream, made current here)
@@ -303,7 +305,7 @@ class FrameRenderer:
             raise TypeError("render_specular: pass a torch.cuda.Stream (or None for the current stream), not a raw handle")
         if stream is not None and stream != torch.cuda.current_stream(self.device):
             with torch.cuda.stream(stream):
-                return self.render_specular(depth, stream)
+                return self.render_specular(depth, stream, path_tracing, path_seed, path_kinds, fused)
         self.d_slots.zero_()
         if path_kinds is None:
             path_kinds = binding.MR_PATH_MIRROR | binding.MR_PATH_REFRACT
@@ -315,6 +317,31 @@ class FrameRenderer:
         for level in range(depth + 1):
             if n == 0:
                 break
+            if fused:
+                last = level == depth
+                fl = (self.flags & binding.MR_MATH_PRODUCT) | (binding.MR_TRACE_INCOHERENT if level > 0 else 0)
+                cnts = torch.zeros(3, dtype=torch.int64, device=self.device)        # rays, shadow rays, children
+                out_rays = out_w = out_pix = out_ids = None
+                if not last:
+                    out_rays = torch.empty((fan * n, 8), **f32)
+                    out_w = torch.empty((fan * n, 3), **f32)
+                    out_pix = torch.empty(fan * n, dtype=torch.int32, device=self.device)
+                    if path_tracing:
+                        out_ids = torch.empty(fan * n, dtype=torch.int32, device=self.device)
+                children = binding.MR_LEVEL_LAST if last else (binding.MR_LEVEL_PATH if path_tracing else binding.MR_LEVEL_SPECULAR)
+                sc.trace_level(rays, weights, pixels, ids, n, self.d_slots, L, W, children=children, d_out_rays=out_rays,
+                               d_out_weights=out_w, d_out_pixels=out_pix, d_out_ids=out_ids,
+                               d_out_count=None if last else cnts[2:], d_counts=cnts[:2], spp=self.spp, flags=fl, seed=path_seed,
+                               bounce=level, kinds=path_kinds, stream=stream)
+                host = cnts.tolist()
+                per_level.append((n, host[1]))
+                if last:
+                    break
+                n = host[2]
+                rays, weights, pixels = out_rays[:n], out_w[:n], out_pix[:n]
+                if path_tracing:
+                    ids = out_ids[:n]
+                continue
             hits = torch.empty((n, 4), **f32)
             sh_rays = torch.empty((n, 8), **f32)
             sh_hits = torch.empty((n, 4), **f32)

@@ -294,6 +294,32 @@ mr_status mr_gen_path_rays(mr_scene *scene, const mr_ray *d_rays, const mr_hit *
                            uint32_t bounce, uint32_t kinds, mr_ray *d_out_rays, float *d_out_weights, uint32_t *d_out_pixels,
                            uint32_t *d_out_ids, uint64_t *d_count, void *stream);
 
+/* ---- one level of Scene::traceScene's recursion (Scene.cpp:270-346) in ONE launch -------------------------------
+ * For every ray of the queue: Scene::trace -> Phong::shade (shadow ray, Scene::trace, the occluder's light scale,
+ * diffuse term + highlight, Phong.cpp:80-156) times the ray's weight, added to its pixel -> the children of the next
+ * level.  The same hit records, shadow rays and children, bit for bit, as
+ *   mr_trace -> mr_gen_shadow_rays -> mr_trace_indirect -> mr_shade_accumulate -> mr_gen_secondary_rays | mr_gen_path_rays
+ * without the buffers between them: the hit stays in the lane's registers, the shadow ray is built from it and traced
+ * by the same lane.  The children arrive in another ORDER than the batched generators' (compare the queues as sets,
+ * by ray id under path tracing); the pixel sums differ by the order of the float atomics, as two runs of
+ * mr_shade_accumulate do.
+ * children: MR_LEVEL_LAST (none: the queue's rays are shaded only; the d_out_* may be NULL), MR_LEVEL_SPECULAR (the
+ * generators of mr_gen_secondary_rays, room for 3n) or MR_LEVEL_PATH (those of mr_gen_path_rays with path_kinds, seed
+ * and bounce as there, room for 4n).  flags: MR_MATH_PRODUCT, MR_TRACE_INCOHERENT.  d_weights / d_pixels / d_ids /
+ * d_out_ids may be NULL as in mr_gen_path_rays.  d_out_count: zeroed by the call, receives the number of children.
+ * d_counts (may be NULL): [0] += rays traced, [1] += shadow rays traced. */
+enum { MR_LEVEL_LAST = 0u, MR_LEVEL_SPECULAR = 1u, MR_LEVEL_PATH = 2u };
+typedef struct mr_level_desc {
+    mr_light light;
+    uint32_t spp, flags, children;
+    uint32_t path_kinds, seed, bounce;
+    uint32_t reserved[4];
+} mr_level_desc;
+mr_status mr_trace_level(mr_scene *scene, const mr_level_desc *level, const mr_ray *d_rays, const float *d_weights,
+                         const uint32_t *d_pixels, const uint32_t *d_ids, uint64_t n, float *d_rgb, mr_ray *d_out_rays,
+                         float *d_out_weights, uint32_t *d_out_pixels, uint32_t *d_out_ids, uint64_t *d_out_count,
+                         uint64_t *d_counts, void *stream);
+
 /* sigmoid(6v-3) tone map + 8-bit quantisation (Scene.cpp:87-91,177-202; Image.cpp:44-50) */
 mr_status mr_tonemap(mr_scene *scene, const float *d_rgb, uint64_t n_values, uint8_t *d_out, void *stream);
 

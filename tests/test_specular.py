@@ -50,7 +50,9 @@ def build_both(oracle, miro):
     return a, b, clamp_like_phong_ctor(mats), prim_mat
 
 
-def test_specular_frame_matches_oracle(oracle, miro):
+@pytest.mark.parametrize("fused", [False, True], ids=["batched", "fused"])
+def test_specular_frame_matches_oracle(oracle, miro, fused):
+    """fused: every level is one launch of mr_trace_level instead of the seven batched calls"""
     import torch
     assert torch.cuda.is_available()
     a, b, mats11, prim_mat = build_both(oracle, miro)
@@ -58,7 +60,7 @@ def test_specular_frame_matches_oracle(oracle, miro):
     W, H, spp = 96, 72, 2
     fr = mframe.FrameRenderer(b, d, W, H, spp=spp)
     fr.generate()
-    levels = fr.render_specular(depth=10)
+    levels = fr.render_specular(depth=10, fused=fused)
     torch.cuda.synchronize()
     rays = oracle.eye_rays(camera_of(oracle, "teapot"), W, H, spp=spp, jitter=True, seed=168)
     want_rays, calls = a.trace_scene(mats11, prim_mat, rays, d["light"], d["wattage"], depth=10)
@@ -76,8 +78,9 @@ def test_specular_frame_matches_oracle(oracle, miro):
     assert scale > 0
 
 
+@pytest.mark.parametrize("fused", [False, True], ids=["batched", "fused"])
 @pytest.mark.parametrize("kinds,depth", [(3, 4), (7, 2)])
-def test_path_traced_frame_matches_oracle(oracle, miro, kinds, depth):
+def test_path_traced_frame_matches_oracle(oracle, miro, kinds, depth, fused):
     """Scene::traceScene as the PATH_TRACING build runs it -- glossy mirror (finite shininess) and rough glass, every child
     drawn from its lobe with the counter-based generator; kinds = 7 adds the diffuse bounce of Ray::random (extension).
     Same ray totals per level as the oracle's recursion makes Scene::trace calls, pixels within the tolerance of the
@@ -93,7 +96,7 @@ def test_path_traced_frame_matches_oracle(oracle, miro, kinds, depth):
     W, H, spp = 64, 48, 2
     fr = mframe.FrameRenderer(b, d, W, H, spp=spp)
     fr.generate()
-    levels = fr.render_specular(depth=depth, path_tracing=True, path_seed=99, path_kinds=kinds)
+    levels = fr.render_specular(depth=depth, path_tracing=True, path_seed=99, path_kinds=kinds, fused=fused)
     torch.cuda.synchronize()
     got = fr.d_rgb.cpu().numpy()
     rays = oracle.eye_rays(camera_of(oracle, "teapot"), W, H, spp=spp, jitter=True, seed=168)
@@ -119,10 +122,12 @@ def test_default_material_equals_direct_shade(oracle, miro):
     fr.generate()
     fr.step()
     ref = fr.d_rgb.clone()
-    levels = fr.render_specular(depth=10)
-    torch.cuda.synchronize()
-    assert len(levels) == 1                       # no specular material: no second level
-    assert torch.allclose(fr.d_rgb, ref, rtol=1e-5, atol=1e-7 * float(ref.max()))
+    for fused in (False, True):
+        levels = fr.render_specular(depth=10, fused=fused)
+        torch.cuda.synchronize()
+        assert len(levels) == 1                       # no specular material: no second level
+        assert levels[0] == fr.ray_counts() if not fused else levels[0][0] == fr.n
+        assert torch.allclose(fr.d_rgb, ref, rtol=1e-5, atol=1e-7 * float(ref.max()))
 
 
 def test_material_argument_checks(miro):
