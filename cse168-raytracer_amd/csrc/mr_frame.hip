@@ -206,7 +206,7 @@ mr_status launch_frame(const DeviceScene &ds, const mr_frame_desc &fd, float *d_
         return any ? launch_frame_t<88, true>(a, stream) : launch_frame_t<88, false>(a, stream);
     }
     if (product) return any ? launch_frame_t<267, true>(a, stream) : launch_frame_t<267, false>(a, stream);
-    return any ? launch_frame_t<282, true>(a, stream) : launch_frame_t<282, false>(a, stream);
+    return any ? launch_frame_t<794, true>(a, stream) : launch_frame_t<794, false>(a, stream);
 }
 
 }  // namespace mr

@@ -406,9 +406,18 @@ mr_status launch_trace(const TraceParams &p, uint32_t flags, hipStream_t stream)
         if (product) return any ? launch_persistent<true, true, false, 16, true>(p, stream) : launch_persistent<true, false, false, 16, true>(p, stream);
         return any ? launch_persistent<true, true, true, 16, true>(p, stream) : launch_persistent<true, false, true, 16, true>(p, stream);
     }
+#ifdef MIRO_DEV
+    // development builds only: MIRO_EXACT_CORRECTION=1 runs the default trace on the correction steps alone (VAR bit 9 clear)
+    static const bool corr_only = getenv("MIRO_EXACT_CORRECTION") && atoi(getenv("MIRO_EXACT_CORRECTION")) != 0;
+    if (corr_only && !product && !vote && !(flags & MR_TRACE_PERSISTENT)) {
+        return any ? launch_trace_t<true, true, false, 282>(p, stream) : launch_trace_t<true, false, false, 282>(p, stream);
+    }
+#endif
     if (vote) {
         // MR_TRACE_INCOHERENT: the voting control flow (VAR bit 6) on the same arithmetic
         if (product) return any ? launch_trace_t<true, true, false, 73>(p, stream) : launch_trace_t<true, false, false, 73>(p, stream);
+        // (on the correction steps alone: incoherent batches are bound by their fetches, and the guard's wave-wide branch
+        // costs them 5 %, profiles/r02_guarded_products_ab.log)
         return any ? launch_trace_t<true, true, false, 88>(p, stream) : launch_trace_t<true, false, false, 88>(p, stream);
     }
     if (flags & MR_TRACE_PERSISTENT) {
@@ -417,8 +426,9 @@ mr_status launch_trace(const TraceParams &p, uint32_t flags, hipStream_t stream)
     }
     // MR_MATH_PRODUCT: slab distances as products with the rounded 1/d (and its development variants)
     if (product) return any ? launch_product<true>(p, stream) : launch_product<false>(p, stream);
-    // default: the reference's quotients by the correction step, while-while, scalar path, octant-specialised (VAR 16 | 2 | 8 | 256)
-    return any ? launch_trace_t<true, true, false, 282>(p, stream) : launch_trace_t<true, false, false, 282>(p, stream);
+    // default: the reference's quotients -- guarded products, correction steps where a decision is close -- while-while,
+    // scalar path, octant-specialised (VAR 16 | 2 | 8 | 256 | 512)
+    return any ? launch_trace_t<true, true, false, 794>(p, stream) : launch_trace_t<true, false, false, 794>(p, stream);
 }
 
 mr_status launch_eye_rays(const mr_camera &cam, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,

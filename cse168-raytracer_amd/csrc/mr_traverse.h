@@ -96,6 +96,18 @@ __device__ __forceinline__ float vmin2(float a, float b) {
     return o;
 }
 
+// |a - b| of two bit patterns as unsigned integers, and a three-way unsigned minimum: one VALU op each
+__device__ __forceinline__ unsigned vsad(float a, float b) {
+    unsigned o;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+}
+__device__ __forceinline__ unsigned vmin3u(unsigned a, unsigned b, unsigned c) {
+    unsigned o;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+    return o;
+}
+
 // min/max slab test of one child box for NaN-free rays on the reference's own products (corner - o) * (1/d):
 // 6 sub + 6 mul + 3 min + 3 max + max3 + min3.  Same entry/exit values as the select chain of slab_axis (up to
 // the sign of a zero, which no comparison sees).
@@ -288,6 +300,9 @@ __device__ __forceinline__ v16f load_node_scalar(const float4 *nodes, int cur_un
 template <bool EXACT, bool STATS, int SLAB, int OCT = 8>
 __device__ __forceinline__ void node_slabs(const float4 q0, const float4 q1, const float4 q2, const RayRegs &r,
                                            float &mn0, float &mx0, float &mn1, float &mx1);
+template <bool EXACT, bool STATS, int SLAB, int OCT = 8>
+__device__ __forceinline__ void node_slabs_guarded(const float4 q0, const float4 q1, const float4 q2, const RayRegs &r, float best_t,
+                                                   float &mn0, float &mx0, float &mn1, float &mx1);
 
 // the post-test bookkeeping of BVH.cpp:609-651: near child first (ties -> child 0), far child pushed, else pop
 template <bool STATS, bool SAFE>
@@ -324,19 +339,19 @@ __device__ __forceinline__ void node_decide(float mn0, float mx0, float mn1, flo
 template <bool EXACT, bool STATS, int SLAB, bool SCALAR = false, int OCT = 8>
 __device__ __forceinline__ void node_step(const TraceParams &p, const RayRegs &r, Lane &L, int *s_stack, int tid, Stats &st) {
     float mn0, mx0, mn1, mx1;
-    constexpr bool kSafe = SLAB == 1 || SLAB == 2 || SLAB == 4;
+    constexpr bool kSafe = SLAB == 1 || SLAB == 2 || SLAB == 4 || SLAB == 5;
     if (SCALAR) {
         const int cur0 = __builtin_amdgcn_readfirstlane(L.cur);
         if (__all(L.cur == cur0)) {
             const v16f v = load_node_scalar(p.nodes, cur0);
             const float4 q0 = make_float4(v[0], v[1], v[2], v[3]), q1 = make_float4(v[4], v[5], v[6], v[7]);
             const float4 q2 = make_float4(v[8], v[9], v[10], v[11]);
-            if (SLAB == 4 && __float_as_int(v[14]) != 0) {   // irregular node (wave-uniform): the reference's own divisions
+            if ((SLAB == 4 || SLAB == 5) && __float_as_int(v[14]) != 0) {   // irregular node (wave-uniform): the reference's own divisions
                 node_slabs<EXACT, STATS, 3>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
                 node_decide<STATS, false>(mn0, mx0, mn1, mx1, __float_as_int(v[12]), __float_as_int(v[13]), r, L, s_stack, st);
                 return;
             }
-            node_slabs<EXACT, STATS, SLAB, OCT>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
+            node_slabs_guarded<EXACT, STATS, SLAB, OCT>(q0, q1, q2, r, L.best_t, mn0, mx0, mn1, mx1);
             node_decide<STATS, kSafe>(mn0, mx0, mn1, mx1, __float_as_int(v[12]), __float_as_int(v[13]), r, L, s_stack, st);
             return;
         }
@@ -345,12 +360,12 @@ __device__ __forceinline__ void node_step(const TraceParams &p, const RayRegs &r
     const float4 *nd = p.nodes + 4 * (size_t)L.cur;
     const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2];
     const int4 q3 = *reinterpret_cast<const int4 *>(nd + 3);
-    if (SLAB == 4 && q3.z != 0) {
+    if ((SLAB == 4 || SLAB == 5) && q3.z != 0) {
         node_slabs<EXACT, STATS, 3>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
         node_decide<STATS, false>(mn0, mx0, mn1, mx1, q3.x, q3.y, r, L, s_stack, st);
         return;
     }
-    node_slabs<EXACT, STATS, SLAB, OCT>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
+    node_slabs_guarded<EXACT, STATS, SLAB, OCT>(q0, q1, q2, r, L.best_t, mn0, mx0, mn1, mx1);
     node_decide<STATS, kSafe>(mn0, mx0, mn1, mx1, q3.x, q3.y, r, L, s_stack, st);
 }
 
@@ -378,6 +393,34 @@ __device__ __forceinline__ void node_slabs(const float4 q0, const float4 q1, con
         slab_box_minmax(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, r, mn0, mx0);
         slab_box_minmax(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, r, mn1, mx1);
     }
+}
+
+// SLAB 5, "guarded products": the slab distances of a regular ray in a regular node as products (corner - o) * RN(1/d)
+// -- 24 VALU fewer per two-child visit than the correction steps of SLAB 4 -- whenever the decisions taken from them are
+// PROVABLY the ones the reference's quotients give, and the quotients themselves otherwise.
+//   * q~ = RN(a * RN(1/d)) = (a/d)(1+e), |e| <= 2^-23 + 2^-48, against q = RN(a/d) = (a/d)(1+e'), |e'| <= 2^-24 (no
+//     under- or overflow: lane_is_regular, regular nodes): q~ and q are less than 4 ulps apart, have the same sign, and
+//     are zero together.  max3 / min3 / min with best_t are monotone, so each of mn0, mx0, mn1, mx1, min(mx, best_t)
+//     computed from products is less than 4 ulps from the same expression on quotients.
+//   * node_decide takes five comparisons from them: mn0 > min(mx0, best), mx0 < tmin, the same two for child 1, and
+//     mn0 > mn1.  Two floats further than 8 ulps apart compare the same way after each moves by less than 4.  The ulp
+//     distance of two floats of one sign is the difference of their bit patterns (v_sad_u32); patterns of opposite sign
+//     are 2^31 apart, and there the comparison is decided by the signs, which are exact.
+//   * so: if in every lane all five pairs are more than 16 patterns apart (margin of two), the product decisions stand;
+//     if any lane has a closer pair the whole wave recomputes the node with exact quotients (SLAB 4) -- about one visit
+//     in a few thousand.
+// Same hits, same visiting order, same bits as SLAB 4 (tests: test_gpu_parity, the fuzz campaigns run both).
+template <bool EXACT, bool STATS, int SLAB, int OCT>
+__device__ __forceinline__ void node_slabs_guarded(const float4 q0, const float4 q1, const float4 q2, const RayRegs &r, float best_t,
+                                                   float &mn0, float &mx0, float &mn1, float &mx1) {
+    if (SLAB != 5) {
+        node_slabs<EXACT, STATS, SLAB, OCT>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
+        return;
+    }
+    node_slabs<EXACT, STATS, 1, OCT>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
+    const float k0 = vmin2(mx0, best_t), k1 = vmin2(mx1, best_t);
+    const unsigned near = vmin3u(vmin3u(vsad(mn0, k0), vsad(mx0, r.tmin), vsad(mn1, k1)), vsad(mx1, r.tmin), vsad(mn0, mn1));
+    if (__any(near <= 16u)) node_slabs<EXACT, STATS, 4, OCT>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
 }
 
 // one 48-byte triangle record through the scalar data cache (all active lanes at the same leaf)
@@ -582,7 +625,8 @@ __device__ __forceinline__ void trace_ray(const TraceParams &p, const RayRegs &r
     // VAR bit 8: when the wave's live rays all point into one octant the slab tests take their near / far corners by
     // position (slab_box_oct): eight copies of the loop, chosen once per ray batch of the wave
     constexpr bool kOct = (VAR & 256) != 0;
-    constexpr int kGoodSlab = kMinMax ? kSafeSlab : 4;
+    constexpr int kExactSlab = (VAR & 512) ? 5 : 4;   // VAR bit 9: guarded products (node_slabs_guarded) instead of the correction steps
+    constexpr int kGoodSlab = kMinMax ? kSafeSlab : kExactSlab;
     const bool good_wave = kMinMax ? __all(lane_is_nan_free(r) || !live) : ((kStrict && !STATS) ? __all(lane_is_regular(r) || !live) : false);
     bool done_oct = false;
     if (kOct && (kMinMax || (kStrict && !STATS)) && good_wave) {
@@ -615,7 +659,7 @@ __device__ __forceinline__ void trace_ray(const TraceParams &p, const RayRegs &r
         // the default trace: exact quotients by the correction step where every lane's ray is regular (then the lanes'
         // quotients are NaN-free too and the min/max form decides like the select form); the reference's own
         // divisions otherwise
-        if (good_wave) traverse<EXACT, ANY, STATS, 4, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
+        if (good_wave) traverse<EXACT, ANY, STATS, kExactSlab, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
         else traverse<EXACT, ANY, STATS, 3, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
     } else {
         traverse<EXACT, ANY, STATS, kBaseSlab, kWW, kStrict && kScalar, kObj>(p, r, L, s_stack, tid, st);

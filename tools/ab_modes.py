@@ -65,7 +65,7 @@ def main():
             same = cs == ref
             bad += 0 if same else 1
             line += "  %s %.3f ms %.2f Grays/s%s" % (name, ms, n / ms / 1e6, "" if same else " DIFFERENT")
-        print(line, flush=True)
+        print(line + "  [checksum %d]" % ref, flush=True)
 
     cam = binding.make_camera(d["eye"], d["lookat"], d["up"], d["fov"])
     for spp in [int(x) for x in a.spp.split(",") if x]:
