@@ -273,16 +273,20 @@ struct Lane {
     __device__ __forceinline__ bool have() const { return cur != kDone; }
 };
 
+// L.sp is the lane's stack pointer as an ABSOLUTE LDS address (the base of the dynamic LDS block is added once, in
+// stack_reset): a push or pop is one ds instruction on that register -- through a generic `s_stack + offset` the compiler
+// emitted a v_add with the (link-time) base in front of every one of them.
+typedef __attribute__((address_space(3))) int lds_int;
 __device__ __forceinline__ void stack_push(Lane &L, int *s_stack, int v) {
-    *reinterpret_cast<int *>(reinterpret_cast<char *>(s_stack) + L.sp) = v;
+    *reinterpret_cast<lds_int *>((unsigned)L.sp) = v;
     L.sp += kStackStride;
 }
 __device__ __forceinline__ int stack_pop(Lane &L, int *s_stack) {
     L.sp -= kStackStride;
-    return *reinterpret_cast<int *>(reinterpret_cast<char *>(s_stack) + L.sp);
+    return *reinterpret_cast<lds_int *>((unsigned)L.sp);
 }
 __device__ __forceinline__ void stack_reset(Lane &L, int *s_stack, int tid) {
-    L.sp = tid * (int)sizeof(int);
+    L.sp = (int)(unsigned)reinterpret_cast<__UINTPTR_TYPE__>((lds_int *)s_stack) + tid * (int)sizeof(int);
     stack_push(L, s_stack, kDone);
 }
 
