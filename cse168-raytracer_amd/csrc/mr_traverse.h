@@ -423,7 +423,12 @@ __device__ __forceinline__ void node_slabs_guarded(const float4 q0, const float4
     }
     node_slabs<EXACT, STATS, 1, OCT>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
     const float k0 = vmin2(mx0, best_t), k1 = vmin2(mx1, best_t);
-    const unsigned near = vmin3u(vmin3u(vsad(mn0, k0), vsad(mx0, r.tmin), vsad(mn1, k1)), vsad(mx1, r.tmin), vsad(mn0, mn1));
+    // smallest of the five pattern distances, in one asm block (separate asm statements are fenced by hazard no-ops)
+    unsigned near, t0, t1;
+    asm("v_sad_u32 %0, %3, %4, 0\n\tv_sad_u32 %1, %5, %6, 0\n\tv_sad_u32 %2, %7, %8, 0\n\tv_min3_u32 %0, %0, %1, %2\n\t"
+        "v_sad_u32 %1, %9, %6, 0\n\tv_sad_u32 %2, %3, %7, 0\n\tv_min3_u32 %0, %0, %1, %2"
+        : "=&v"(near), "=&v"(t0), "=&v"(t1)
+        : "v"(mn0), "v"(k0), "v"(mx0), "v"(r.tmin), "v"(mn1), "v"(k1), "v"(mx1));
     if (__any(near <= 16u)) node_slabs<EXACT, STATS, 4, OCT>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
 }
 
