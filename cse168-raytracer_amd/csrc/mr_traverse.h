@@ -665,9 +665,9 @@ __device__ __forceinline__ void trace_ray(const TraceParams &p, const RayRegs &r
         if (good_wave) traverse<EXACT, ANY, STATS, kSafeSlab, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
         else traverse<EXACT, ANY, STATS, 0, kWW, false, kObj>(p, r, L, s_stack, tid, st);
     } else if (kStrict && !STATS) {
-        // the default trace: exact quotients by the correction step where every lane's ray is regular (then the lanes'
-        // quotients are NaN-free too and the min/max form decides like the select form); the reference's own
-        // divisions otherwise
+        // the default trace: where every lane's ray is regular, the quotients' decisions from guarded products (VAR bit 9)
+        // or from the correction steps (then the lanes' quotients are NaN-free too and the min/max form decides like the
+        // select form); the reference's own divisions otherwise
         if (good_wave) traverse<EXACT, ANY, STATS, kExactSlab, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
         else traverse<EXACT, ANY, STATS, 3, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
     } else {

@@ -105,11 +105,13 @@ enum {
                                       instead of running node tests until its slowest lane has found a leaf.  Same per-ray
                                       steps in the same order: identical hit records.  Combines with MR_TRACE_PERSISTENT */
     MR_MATH_PRODUCT   = 1u << 6    /* slab distances as products (corner - o) * RN(1/d) instead of the reference's
-                                      quotients (corner - o) / d (BVH.cpp:601-602), which the default reproduces bit for
-                                      bit (one fma correction step per product: exactly the correctly rounded quotient
-                                      for operands in the normal range; literal divisions otherwise).  A product differs
-                                      from the quotient by <= 3 ulp, which can flip a box comparison only on an exact
-                                      tie (observed: 0 of 3e8 rays in normal use, 2 of 1.3e8 when tMax is set one ulp
+                                      quotients (corner - o) / d (BVH.cpp:601-602), whose decisions the default reproduces
+                                      exactly (products where the visit's comparisons are more than 16 ulp from a tie --
+                                      provably the quotients' outcome --, one fma correction step per product otherwise:
+                                      exactly the correctly rounded quotient for operands in the normal range; literal
+                                      divisions for the rest).  A product differs
+                                      from the quotient by <= 3 ulp, which can flip a box comparison only on a
+                                      near-tie (observed: 0 of 3e8 rays in normal use, 2 of 1.3e8 when tMax is set one ulp
                                       above a known hit); t / beta / gamma of a hit are the same bits either way.
                                       About 25 % faster */
 };
