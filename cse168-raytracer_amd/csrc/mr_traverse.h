@@ -668,7 +668,9 @@ __device__ __forceinline__ void trace_ray(const TraceParams &p, const RayRegs &r
         // the default trace: where every lane's ray is regular, the quotients' decisions from guarded products (VAR bit 9)
         // or from the correction steps (then the lanes' quotients are NaN-free too and the min/max form decides like the
         // select form); the reference's own divisions otherwise
-        if (good_wave) traverse<EXACT, ANY, STATS, kExactSlab, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
+        // (a wave whose rays point into several octants is an incoherent one: bound by its record fetches, it gains nothing
+        // from the guarded products and would pay for their wave-wide branch -- the correction steps alone here)
+        if (good_wave) traverse<EXACT, ANY, STATS, 4, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
         else traverse<EXACT, ANY, STATS, 3, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
     } else {
         traverse<EXACT, ANY, STATS, kBaseSlab, kWW, kStrict && kScalar, kObj>(p, r, L, s_stack, tid, st);
