@@ -427,8 +427,8 @@ mr_status launch_trace(const TraceParams &p, uint32_t flags, hipStream_t stream)
     // MR_MATH_PRODUCT: slab distances as products with the rounded 1/d (and its development variants)
     if (product) return any ? launch_product<true>(p, stream) : launch_product<false>(p, stream);
     // default: the reference's quotients -- guarded products, correction steps where a decision is close -- while-while,
-    // scalar path, octant-specialised (VAR 16 | 2 | 8 | 256 | 512)
-    return any ? launch_trace_t<true, true, false, 794>(p, stream) : launch_trace_t<true, false, false, 794>(p, stream);
+    // scalar path, octant-specialised; waves whose rays point into several octants vote (VAR 16 | 2 | 8 | 256 | 512 | 1024)
+    return any ? launch_trace_t<true, true, false, 1818>(p, stream) : launch_trace_t<true, false, false, 1818>(p, stream);
 }
 
 mr_status launch_eye_rays(const mr_camera &cam, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,

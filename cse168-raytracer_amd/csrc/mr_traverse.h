@@ -670,7 +670,10 @@ __device__ __forceinline__ void trace_ray(const TraceParams &p, const RayRegs &r
         // select form); the reference's own divisions otherwise
         // (a wave whose rays point into several octants is an incoherent one: bound by its record fetches, it gains nothing
         // from the guarded products and would pay for their wave-wide branch -- the correction steps alone here)
-        if (good_wave) traverse<EXACT, ANY, STATS, 4, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
+        // VAR bit 10: ... and the voting control flow suits it better (random rays 3.86 -> 4.09 Grays/s, the atrium's bounce
+        // rays 4.96 -> 5.31, 1-spp shadow rays in image order 3.73 -> 4.31 without the caller's MR_TRACE_INCOHERENT hint)
+        constexpr int kMixedFlow = ((VAR & 1024) && kWW == 1) ? 2 : kWW;
+        if (good_wave) traverse<EXACT, ANY, STATS, 4, kMixedFlow, kScalar, kObj>(p, r, L, s_stack, tid, st);
         else traverse<EXACT, ANY, STATS, 3, kWW, kScalar, kObj>(p, r, L, s_stack, tid, st);
     } else {
         traverse<EXACT, ANY, STATS, kBaseSlab, kWW, kStrict && kScalar, kObj>(p, r, L, s_stack, tid, st);
