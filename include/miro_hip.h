@@ -103,7 +103,9 @@ enum {
                                       random or 1-sample-per-pixel batches).  Selects the voting control flow: every
                                       iteration a wave runs the step (node test / triangle test) most of its lanes need,
                                       instead of running node tests until its slowest lane has found a leaf.  Same per-ray
-                                      steps in the same order: identical hit records.  Combines with MR_TRACE_PERSISTENT */
+                                      steps in the same order: identical hit records.  Combines with MR_TRACE_PERSISTENT.
+                                      Without the hint the default kernel decides per wave: a wave whose rays point into
+                                      several octants votes, one whose rays share an octant does not */
     MR_MATH_PRODUCT   = 1u << 6    /* slab distances as products (corner - o) * RN(1/d) instead of the reference's
                                       quotients (corner - o) / d (BVH.cpp:601-602), whose decisions the default reproduces
                                       exactly (products where the visit's comparisons are more than 16 ulp from a tie --
