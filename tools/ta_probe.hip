@@ -10,6 +10,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 __device__ __forceinline__ int quad_bcast(int v, int k) {
@@ -61,13 +64,13 @@ int main(int argc, char **argv) {
     srand(7);
     for (auto &v : h) { unsigned r = (unsigned)rand(); v = make_float4(1.f, 2.f, 3.f, 0.f); __builtin_memcpy(&v.w, &r, 4); }
     float4 *d_t; float *d_o;
-    hipMalloc(&d_t, h.size() * sizeof(float4)); hipMalloc(&d_o, lanes * sizeof(float));
-    hipMemcpy(d_t, h.data(), h.size() * sizeof(float4), hipMemcpyHostToDevice);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    CK(hipMalloc(&d_t, h.size() * sizeof(float4))); CK(hipMalloc(&d_o, lanes * sizeof(float)));
+    CK(hipMemcpy(d_t, h.data(), h.size() * sizeof(float4), hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int mode = 0; mode < 5; mode++) {
         float best = 1e30f;
         for (int rep = 0; rep < 3; rep++) {
-            hipEventRecord(e0);
+            CK(hipEventRecord(e0));
             switch (mode) {
                 case 0: hipLaunchKernelGGL(probe<0>, dim3(lanes / 256), dim3(256), 0, 0, d_t, n_rec, iters, d_o); break;
                 case 1: hipLaunchKernelGGL(probe<1>, dim3(lanes / 256), dim3(256), 0, 0, d_t, n_rec, iters, d_o); break;
@@ -75,8 +78,8 @@ int main(int argc, char **argv) {
                 case 3: hipLaunchKernelGGL(probe<3>, dim3(lanes / 256), dim3(256), 0, 0, d_t, n_rec, iters, d_o); break;
                 default: hipLaunchKernelGGL(probe<4>, dim3(lanes / 256), dim3(256), 0, 0, d_t, n_rec, iters, d_o); break;
             }
-            hipEventRecord(e1); hipEventSynchronize(e1);
-            float ms; hipEventElapsedTime(&ms, e0, e1);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (ms < best) best = ms;
         }
         const double fetches = (double)lanes * iters;
