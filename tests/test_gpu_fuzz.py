@@ -272,3 +272,59 @@ def test_random_scene_fused_frame_equals_batched_pipeline(miro, seed):
                 full[rows] = part.d_rgb.view(len(rows), W, 3)
         torch.cuda.synchronize()
         assert _same_bits_or_nan(full.view(-1, 3).cpu().numpy(), ref.d_rgb.cpu().numpy())
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_scene_level_equals_batched_calls(miro, seed):
+    """mr_trace_level (one launch per level of traceScene's recursion) against the batched calls on the same random scenes
+    with random materials -- mirrors, glass, glossy lobes, zero-area triangles (NaN normals), spheres, planes: two levels,
+    either build of the generators, children compared as sets bit for bit, equal ray counts, pixel sums within the order of
+    the float atomics."""
+    import torch
+    from miro_amd import binding
+    from miro_amd import frame as mframe
+    from test_level import batched_level, canon, fused_level
+    rng = np.random.default_rng(BASE + 500000 + seed)
+    steps, leaf, extent = make_scene(rng)
+    sc = replay(miro.Scene(), steps, leaf)
+    n_tri = sum(len(st[3]) for st in steps if st[0] == "mesh") + sum(1 for st in steps if st[0] == "sphere")
+    n_mat = int(rng.integers(1, 6))
+    mats = []
+    for _ in range(n_mat):
+        kd = tuple(float(x) for x in rng.random(3))
+        ks = tuple(float(x) for x in rng.random(3) * rng.choice([0.0, 0.6])) 
+        kt = tuple(float(x) for x in rng.random(3) * rng.choice([0.0, 0.9]))
+        mats.append((kd, ks, kt, float(rng.choice([1.0, 5.0, 200.0, float("inf")])), float(rng.choice([1.0, 1.33, 1.5]))))
+    sc.set_materials(mats, rng.integers(0, n_mat, n_tri).astype(np.uint32))
+    eye = ((rng.random(3) - 0.5) * 4 * extent).astype(np.float32)
+    desc = dict(eye=[float(x) for x in eye], lookat=[float(x) for x in (rng.random(3) - 0.5) * extent], up=[0.0, 1.0, 0.0],
+                fov=float(rng.choice([45.0, 90.0])), light=[float(x) for x in (rng.random(3) - 0.5) * 3 * extent], wattage=700.0)
+    W, H, spp = int(rng.integers(8, 70)), int(rng.integers(8, 60)), int(rng.choice([1, 2, 4]))
+    fr = mframe.FrameRenderer(sc, desc, W, H, spp=spp, tiled=bool(rng.random() < 0.5))
+    fr.generate()
+    path = bool(rng.random() < 0.5)
+    children = binding.MR_LEVEL_PATH if path else binding.MR_LEVEL_SPECULAR
+    kinds = int(rng.integers(1, 8))
+    flags0 = int(rng.choice([0, miro.MR_MATH_PRODUCT]))
+    rays, weights, pixels, ids, n = fr.d_rays, None, None, None, fr.n
+    L, Wt = desc["light"], desc["wattage"]
+    # (tiled order: ray k belongs to pixel SLOT k // spp, which is all the level calls need)
+    for level in range(2):
+        fl = flags0 | (miro.MR_TRACE_INCOHERENT if level else 0)
+        rgb_b, ns_b, out_b = batched_level(torch, sc, rays, weights, pixels, ids, n, L, Wt, spp, fl, children, level, 31, kinds)
+        rgb_f, ns_f, out_f = fused_level(torch, sc, rays, weights, pixels, ids, n, L, Wt, spp, fl, children, level, 31, kinds, rgb_b.shape[0])
+        assert ns_b == ns_f
+        a, b = rgb_b.cpu().numpy(), rgb_f.cpu().numpy()
+        fin = np.isfinite(a) & np.isfinite(b)
+        assert np.array_equal(np.isfinite(a), np.isfinite(b))
+        scale = float(np.abs(a[fin]).max()) if fin.any() else 0.0
+        assert np.allclose(a[fin], b[fin], rtol=1e-4, atol=1e-5 * scale)
+        with_ids = children == binding.MR_LEVEL_PATH
+        qa = canon(*[o.cpu().numpy() for o in (out_b if with_ids else out_b[:3])])
+        qb = canon(*[o.cpu().numpy() for o in (out_f if with_ids else out_f[:3])])
+        assert np.array_equal(qa, qb)
+        n = len(out_b[0])
+        if n == 0:
+            break
+        rays, weights, pixels = out_b[0].contiguous(), out_b[1].contiguous(), out_b[2].contiguous()
+        ids = out_b[3].contiguous() if with_ids else None
