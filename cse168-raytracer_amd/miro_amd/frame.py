@@ -297,7 +297,9 @@ class FrameRenderer:
         235-239; path_kinds |= MR_PATH_DIFFUSE adds Ray::random's bounce, an extension) with stable ray ids handed down
         the levels so that every child's random numbers are those of the oracle's recursion.
         fused: every level is ONE launch of mr_trace_level (trace, shadow ray, trace, shade, children) instead of the seven
-        of the batched calls -- the same rays and children; no hit or shadow-ray buffer exists."""
+        of the batched calls -- the same rays and children; no hit or shadow-ray buffer exists.  fused="auto": the first
+        level in one launch, a later level only if at least 90 % of the previous level's rays hit something (the one-launch
+        form runs its second traversal and its generators at the hit rate of the queue, profiles/r02_level_probe.log)."""
         sc, L, W = self.scene, self.desc["light"], self.desc["wattage"]
         # this driver mixes library launches (on `stream`) with torch ops and .item() read-backs: they only order against
         # each other on torch's current stream, so `stream` must be that stream (or a torch Stream, made current here)
@@ -317,7 +319,7 @@ class FrameRenderer:
         for level in range(depth + 1):
             if n == 0:
                 break
-            if fused:
+            if fused is True or (fused == "auto" and (level == 0 or per_level[-1][1] >= 0.9 * per_level[-1][0])):
                 last = level == depth
                 fl = (self.flags & binding.MR_MATH_PRODUCT) | (binding.MR_TRACE_INCOHERENT if level > 0 else 0)
                 cnts = torch.zeros(3, dtype=torch.int64, device=self.device)        # rays, shadow rays, children

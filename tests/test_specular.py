@@ -50,7 +50,7 @@ def build_both(oracle, miro):
     return a, b, clamp_like_phong_ctor(mats), prim_mat
 
 
-@pytest.mark.parametrize("fused", [False, True], ids=["batched", "fused"])
+@pytest.mark.parametrize("fused", [False, True, "auto"], ids=["batched", "fused", "auto"])
 def test_specular_frame_matches_oracle(oracle, miro, fused):
     """fused: every level is one launch of mr_trace_level instead of the seven batched calls"""
     import torch

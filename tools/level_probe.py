@@ -34,7 +34,7 @@ def main():
     fr.generate()
     torch.cuda.synchronize()
     res = {}
-    for fused in (False, True):
+    for fused in (False, True, "auto"):
         levels = fr.render_specular(depth=a.depth, path_tracing=True, path_seed=5, path_kinds=a.kinds, fused=fused)   # warm-up
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -45,7 +45,7 @@ def main():
         rays = sum(n + s for n, s in levels)
         res[fused] = (ms, levels, fr.d_rgb.clone())
         print("%s %dx%dx%d depth %d kinds %d, %-8s %8.3f ms/frame  %7.2f Grays/s  levels %s" %
-              (a.scene, a.w, a.h, a.spp, a.depth, a.kinds, "fused" if fused else "batched", ms, rays / ms / 1e6, levels), flush=True)
+              (a.scene, a.w, a.h, a.spp, a.depth, a.kinds, {False: "batched", True: "fused", "auto": "auto"}[fused], ms, rays / ms / 1e6, levels), flush=True)
     assert res[False][1] == res[True][1], "ray counts differ"
     scale = float(res[False][2].abs().max())
     err = float((res[False][2] - res[True][2]).abs().max())
