@@ -51,7 +51,8 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(7, 
     Stats st = {0ull, 0ull};
     unsigned my_shadow_rays = 0;
 
-    for (unsigned long long idx = (unsigned long long)blockIdx.x * kTraceBlock + tid; idx < n_round; idx += stride) {
+    const unsigned bid = xcd_block_id();
+    for (unsigned long long idx = (unsigned long long)bid * kTraceBlock + tid; idx < n_round; idx += stride) {
         const bool live = idx < n;
         uint32_t x = 0, row = 0, y = 0, sm = 0;
         float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(1.f, 1.f, 1.f, -1.f);

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(TraceParams p) {
     if (p.n_dev) { const unsigned long long nd = *p.n_dev; if (nd < n_rays) n_rays = nd; }
     const unsigned long long n_round = kWW ? ((n_rays + 63ull) & ~63ull) : n_rays;   // whole waves for __any
 
-    for (unsigned long long idx = (unsigned long long)blockIdx.x * kTraceBlock + tid; idx < n_round; idx += stride) {
+    for (unsigned long long idx = (unsigned long long)xcd_block_id() * kTraceBlock + tid; idx < n_round; idx += stride) {
         const bool live = idx < n_rays;
         // two dwordx4 loads per lane, 32-byte stride: every byte of the fetched lines is used
         float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(1.f, 1.f, 1.f, -1.f);

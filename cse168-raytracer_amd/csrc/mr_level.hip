@@ -64,7 +64,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(6, 
     Stats st = {0ull, 0ull};
     unsigned my_shadow_rays = 0;
 
-    for (unsigned long long k = (unsigned long long)blockIdx.x * kTraceBlock + tid; k < n_round; k += stride) {
+    for (unsigned long long k = (unsigned long long)xcd_block_id() * kTraceBlock + tid; k < n_round; k += stride) {
         const bool live = k < n;
         float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(1.f, 1.f, 1.f, -1.f);
         if (live) { ra = reinterpret_cast<const float4 *>(a.tp.rays)[2 * k]; rb = reinterpret_cast<const float4 *>(a.tp.rays)[2 * k + 1]; }
