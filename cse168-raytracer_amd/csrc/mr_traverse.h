@@ -24,10 +24,10 @@ constexpr int kBlock = 256;          // 4 waves per workgroup
 constexpr int kTraceBlock = MIRO_TRACE_BLOCK;   // threads per workgroup of the trace kernels (their LDS stack is [depth][kTraceBlock])
 constexpr int kTraceGridCap = 32768; // workgroups per trace launch (see launch_trace_t)
 
-// Workgroup ids go round-robin to the 8 XCDs, each with its own 4 MB L2 (the atrium's nodes and triangles are 6.7 MB).
-// In the plain order every XCD traces every eighth 256-ray chunk of the whole image; here an XCD gets runs of kXcdRun
-// consecutive chunks -- one region of the image, one part of the tree in its L2: +4.9 % on the bench frame, +3 % at 16 and
-// 4 spp (profiles/r02_xcd_runs.log).  Only for grids of kXcdMinGrid workgroups or more: a 1-spp frame is 8 100 workgroups,
+// Workgroup ids go round-robin to the 8 XCDs, each with its own L2 (not coherent with the others').  In the plain order
+// every XCD traces every eighth 256-ray chunk of the whole image; here an XCD gets runs of kXcdRun consecutive chunks --
+// one region of the image, whole cache lines of the output to itself: +4.9 % on the bench frame, +3 % at 16 and 4 spp
+// (profiles/r02_xcd_runs.log; DESIGN.md section 4.14 for what the counters show).  Only for grids of kXcdMinGrid workgroups or more: a 1-spp frame is 8 100 workgroups,
 // little more than four per resident slot, and there the uneven cost of the regions shows as idle XCDs (-5 %).
 constexpr unsigned kXcdRun = 64, kXcdMinGrid = 16384;
 __device__ __forceinline__ unsigned xcd_block_id() {
