@@ -200,7 +200,7 @@ mr_status launch_frame(const DeviceScene &ds, const mr_frame_desc &fd, float *d_
         return fail(MR_ERR_INVALID, "mr_render_direct: flags may hold MR_TRACE_ANY, MR_MATH_PRODUCT, MR_TRACE_INCOHERENT only");
     if (ds.n_planes || ds.n_spheres) {
         if (product) return any ? launch_frame_t<43, true>(a, stream) : launch_frame_t<43, false>(a, stream);
-        return any ? launch_frame_t<58, true>(a, stream) : launch_frame_t<58, false>(a, stream);
+        return any ? launch_frame_t<826, true>(a, stream) : launch_frame_t<826, false>(a, stream);
     }
     if (vote) {
         if (product) return any ? launch_frame_t<73, true>(a, stream) : launch_frame_t<73, false>(a, stream);

@@ -394,7 +394,7 @@ mr_status launch_trace(const TraceParams &p, uint32_t flags, hipStream_t stream)
             return any ? launch_trace_t<true, true, false, 120>(p, stream) : launch_trace_t<true, false, false, 120>(p, stream);
         }
         if (product) return any ? launch_trace_t<true, true, false, 43>(p, stream) : launch_trace_t<true, false, false, 43>(p, stream);
-        return any ? launch_trace_t<true, true, false, 58>(p, stream) : launch_trace_t<true, false, false, 58>(p, stream);
+        return any ? launch_trace_t<true, true, false, 826>(p, stream) : launch_trace_t<true, false, false, 826>(p, stream);
     }
     if (stats) {
         // counting mode is diagnostic: always the literal-division kernel in the reference's control flow

@@ -200,7 +200,7 @@ mr_status launch_level(const DeviceScene &ds, const mr_level_desc &ld, const mr_
     a.counts = d_counts;
 
     const bool product = ld.flags & MR_MATH_PRODUCT, vote = ld.flags & MR_TRACE_INCOHERENT;
-    if (ds.n_planes || ds.n_spheres) return product ? launch_level_c<43>(a, ld.children, stream) : launch_level_c<58>(a, ld.children, stream);
+    if (ds.n_planes || ds.n_spheres) return product ? launch_level_c<43>(a, ld.children, stream) : launch_level_c<826>(a, ld.children, stream);
     if (vote) return product ? launch_level_c<73>(a, ld.children, stream) : launch_level_c<88>(a, ld.children, stream);
     return product ? launch_level_c<267>(a, ld.children, stream) : launch_level_c<1818>(a, ld.children, stream);
 }
