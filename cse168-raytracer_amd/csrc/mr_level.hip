@@ -52,7 +52,7 @@ struct LevelArgs {
 // 80 registers (6 waves per SIMD): the generators' double arithmetic spills a few values to scratch rather than costing
 // the two traversals their occupancy.
 template <int VAR, int CHILDREN>
-__global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void level_kernel(LevelArgs a) {
+__global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(CHILDREN == 2 ? 5 : 6, 8))) void level_kernel(LevelArgs a) {
     extern __shared__ int s_stack[];                  // [stack_depth][kTraceBlock]
     __shared__ unsigned s_shadow_rays[kTraceBlock / 64];
     const int tid = threadIdx.x;

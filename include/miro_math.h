@@ -38,6 +38,13 @@
 #define MM_LN2_HI 6.93147180369123816490e-01  /* ln 2 with the low 21 bits cleared */
 #define MM_LN2_LO 1.90821492927058770002e-10  /* ln 2 - MM_LN2_HI */
 
+/* the Newton loops stay loops: unrolled inside the fused level kernel they cost it ~60 more spilled registers */
+#if defined(__clang__)
+#define MM_NOUNROLL _Pragma("clang loop unroll(disable)")
+#else
+#define MM_NOUNROLL
+#endif
+
 /* sin and cos of r, |r| <= pi/4 + a little: Taylor series to r^19 / r^18 (truncation < 1e-19) */
 MM_FN double mm_sin_poly(double r) {
     const double z = r * r;
@@ -80,12 +87,16 @@ MM_FN void mm_sincos(double x, double *s, double *c) {
     }
 }
 
-/* asin(t), 0 <= t <= 1: Newton's iteration on sin from a cubic guess for t <= 0.75, the half-angle identity above */
+/* asin(t), 0 <= t <= 1: Newton's iteration on sin from a cubic guess for t <= 0.75, the half-angle identity above.
+ * The guess is off by < 0.029 (t <= 0.75) / < 4e-4 (h <= 0.354) and every step squares the error (times tan p / 2 < 0.6):
+ * four / three steps reach the last bit of a double (measured against libm on 4 M arguments: 3.3e-16; one step fewer:
+ * 5.6e-15 / 7.8e-16), and the float results equal those of six / five steps on every one of them. */
 MM_FN double mm_asin01(double t) {
     if (t > 0.75) {
         const double h = MM_SQRT((1.0 - t) * 0.5);          /* asin t = pi/2 - 2 asin sqrt((1-t)/2), argument <= 0.354 */
         double p = h + (h * h * h) * (1.0 / 6.0);
-        for (int i = 0; i < 5; i++) {
+        MM_NOUNROLL
+        for (int i = 0; i < 3; i++) {
             double s, c;
             mm_sincos(p, &s, &c);
             p = p - (s - h) / c;
@@ -93,7 +104,8 @@ MM_FN double mm_asin01(double t) {
         return (MM_PI_2_HI - 2.0 * p) + MM_PI_2_LO;
     }
     double p = t + (t * t * t) * (1.0 / 6.0);
-    for (int i = 0; i < 6; i++) {
+    MM_NOUNROLL
+    for (int i = 0; i < 4; i++) {
         double s, c;
         mm_sincos(p, &s, &c);
         p = p - (s - t) / c;
