@@ -49,8 +49,10 @@ struct LevelArgs {
 };
 
 // VAR: the traversal variant of trace_ray (mr_traverse.h) for both rays; CHILDREN: 0 none, 1 specular, 2 path tracing.
-// 80 registers (6 waves per SIMD): the generators' double arithmetic spills a few values to scratch rather than costing
-// the two traversals their occupancy.
+// 80 registers (6 waves per SIMD): the generators spill a few values to scratch rather than costing the two traversals
+// their occupancy.  The path-tracing form gets 96 (5 waves): its double arithmetic also keeps ~280 constants' worth of
+// SGPRs spilled into VGPR lanes, and with 77-94 spilled VGPRs on top of that under an 80-register cap a build of this
+// kernel faulted on the GPU; at 96 it spills <= 18 (tests/test_build_budget.py keeps every kernel below 48).
 template <int VAR, int CHILDREN>
 __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(CHILDREN == 2 ? 5 : 6, 8))) void level_kernel(LevelArgs a) {
     extern __shared__ int s_stack[];                  // [stack_depth][kTraceBlock]
