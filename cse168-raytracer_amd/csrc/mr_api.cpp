@@ -253,7 +253,7 @@ using namespace mr;
 extern "C" {
 
 const char *mr_last_error(void) { return g_err; }
-const char *mr_version(void) { return "miro_hip 0.1 (gfx950)"; }
+const char *mr_version(void) { return "miro_hip 0.2 (gfx950)"; }
 
 mr_status mr_scene_create(int32_t device, mr_scene **out) {
     if (!out) return fail(MR_ERR_INVALID, "out is NULL");
