@@ -45,32 +45,40 @@
 #define MM_NOUNROLL
 #endif
 
-/* sin and cos of r, |r| <= pi/4 + a little: Taylor series to r^19 / r^18 (truncation < 1e-19) */
+/* sin and cos of r, |r| <= pi/4 + a little: Taylor series to r^19 / r^18 (truncation < 1e-19), Horner in r^2 from the
+ * highest term down.  (These two are short and called four times per child: their loops may unroll; the longer series of
+ * asin, log and exp stay loops over their tables, see MM_NOUNROLL.) */
 MM_FN double mm_sin_poly(double r) {
+    static const double c[9] = {
+        1.0 / 6.0,                      /* 1/3! */
+        -1.0 / 120.0,                   /* 1/5! */
+        1.0 / 5040.0,                   /* 1/7! */
+        -1.0 / 362880.0,                /* 1/9! */
+        1.0 / 39916800.0,               /* 1/11! */
+        -1.0 / 6227020800.0,            /* 1/13! */
+        1.0 / 1307674368000.0,          /* 1/15! */
+        -1.0 / 355687428096000.0,       /* 1/17! */
+        1.0 / 121645100408832000.0};    /* 1/19! */
     const double z = r * r;
-    double s = 1.0 / 121645100408832000.0;                 /* 1/19! */
-    s = s * z - 1.0 / 355687428096000.0;                   /* 1/17! */
-    s = s * z + 1.0 / 1307674368000.0;                     /* 1/15! */
-    s = s * z - 1.0 / 6227020800.0;                        /* 1/13! */
-    s = s * z + 1.0 / 39916800.0;                          /* 1/11! */
-    s = s * z - 1.0 / 362880.0;                            /* 1/9! */
-    s = s * z + 1.0 / 5040.0;                              /* 1/7! */
-    s = s * z - 1.0 / 120.0;                               /* 1/5! */
-    s = s * z + 1.0 / 6.0;                                 /* 1/3! */
+    double s = c[8];
+    for (int i = 7; i >= 0; i--) s = s * z + c[i];          /* nine terms: unrolled by the compiler, constants in registers */
     return r - (r * z) * s;
 }
 MM_FN double mm_cos_poly(double r) {
+    static const double c[9] = {
+        0.5,                            /* 1/2! */
+        -1.0 / 24.0,                    /* 1/4! */
+        1.0 / 720.0,                    /* 1/6! */
+        -1.0 / 40320.0,                 /* 1/8! */
+        1.0 / 3628800.0,                /* 1/10! */
+        -1.0 / 479001600.0,             /* 1/12! */
+        1.0 / 87178291200.0,            /* 1/14! */
+        -1.0 / 20922789888000.0,        /* 1/16! */
+        1.0 / 6402373705728000.0};      /* 1/18! */
     const double z = r * r;
-    double c = 1.0 / 6402373705728000.0;                   /* 1/18! */
-    c = c * z - 1.0 / 20922789888000.0;                    /* 1/16! */
-    c = c * z + 1.0 / 87178291200.0;                       /* 1/14! */
-    c = c * z - 1.0 / 479001600.0;                         /* 1/12! */
-    c = c * z + 1.0 / 3628800.0;                           /* 1/10! */
-    c = c * z - 1.0 / 40320.0;                             /* 1/8! */
-    c = c * z + 1.0 / 720.0;                               /* 1/6! */
-    c = c * z - 1.0 / 24.0;                                /* 1/4! */
-    c = c * z + 0.5;                                       /* 1/2! */
-    return 1.0 - z * c;
+    double p = c[8];
+    for (int i = 7; i >= 0; i--) p = p * z + c[i];
+    return 1.0 - z * p;
 }
 
 /* sin(x), cos(x) for |x| <= 16 (the callers pass [0, 2 pi] and [0, pi/2]) */
@@ -129,17 +137,11 @@ MM_FN double mm_log(double x) {
     memcpy(&m, &b, 8);
     if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
     const double s = (m - 1.0) / (m + 1.0), z = s * s;     /* |s| <= 0.1716 */
-    double p = 1.0 / 23.0;
-    p = p * z + 1.0 / 21.0;
-    p = p * z + 1.0 / 19.0;
-    p = p * z + 1.0 / 17.0;
-    p = p * z + 1.0 / 15.0;
-    p = p * z + 1.0 / 13.0;
-    p = p * z + 1.0 / 11.0;
-    p = p * z + 1.0 / 9.0;
-    p = p * z + 1.0 / 7.0;
-    p = p * z + 1.0 / 5.0;
-    p = p * z + 1.0 / 3.0;
+    static const double c[11] = {1.0 / 3.0, 1.0 / 5.0, 1.0 / 7.0, 1.0 / 9.0, 1.0 / 11.0, 1.0 / 13.0, 1.0 / 15.0, 1.0 / 17.0,
+                                 1.0 / 19.0, 1.0 / 21.0, 1.0 / 23.0};
+    double p = c[10];
+    MM_NOUNROLL
+    for (int i = 9; i >= 0; i--) p = p * z + c[i];
     const double lm = 2.0 * s + 2.0 * (s * z) * p;
     return (e * MM_LN2_HI + lm) + e * MM_LN2_LO;
 }
@@ -149,25 +151,13 @@ MM_FN double mm_exp(double z) {
     const double kf = z * (1.0 / 0.6931471805599453);
     const int k = (int)(kf < 0 ? kf - 0.5 : kf + 0.5);
     const double r = (z - k * MM_LN2_HI) - k * MM_LN2_LO;
-    double p = 1.0 / 6402373705728000.0;                   /* 1/18! */
-    p = p * r + 1.0 / 355687428096000.0;
-    p = p * r + 1.0 / 20922789888000.0;
-    p = p * r + 1.0 / 1307674368000.0;
-    p = p * r + 1.0 / 87178291200.0;
-    p = p * r + 1.0 / 6227020800.0;
-    p = p * r + 1.0 / 479001600.0;
-    p = p * r + 1.0 / 39916800.0;
-    p = p * r + 1.0 / 3628800.0;
-    p = p * r + 1.0 / 362880.0;
-    p = p * r + 1.0 / 40320.0;
-    p = p * r + 1.0 / 5040.0;
-    p = p * r + 1.0 / 720.0;
-    p = p * r + 1.0 / 120.0;
-    p = p * r + 1.0 / 24.0;
-    p = p * r + 1.0 / 6.0;
-    p = p * r + 0.5;
-    p = p * r + 1.0;
-    p = p * r + 1.0;
+    static const double c[19] = {
+        1.0, 1.0, 0.5, 1.0 / 6.0, 1.0 / 24.0, 1.0 / 120.0, 1.0 / 720.0, 1.0 / 5040.0, 1.0 / 40320.0, 1.0 / 362880.0,
+        1.0 / 3628800.0, 1.0 / 39916800.0, 1.0 / 479001600.0, 1.0 / 6227020800.0, 1.0 / 87178291200.0,
+        1.0 / 1307674368000.0, 1.0 / 20922789888000.0, 1.0 / 355687428096000.0, 1.0 / 6402373705728000.0};   /* 1/k! */
+    double p = c[18];
+    MM_NOUNROLL
+    for (int i = 17; i >= 0; i--) p = p * r + c[i];
     const uint64_t sb = (uint64_t)(k + 1023) << 52;         /* 2^k, k in the normal range for the callers' arguments */
     double scale;
     memcpy(&scale, &sb, 8);
