@@ -149,8 +149,14 @@ mr_status launch_frame_t(const FrameArgs &a, hipStream_t stream) {
 
 }  // namespace
 
-mr_status launch_frame(const DeviceScene &ds, const mr_frame_desc &fd, float *d_rgb, mr_hit *d_hits, mr_hit *d_shadow_hits,
-                       unsigned long long *d_counts, hipStream_t stream) {
+// This file is compiled twice (Makefile): with 256-thread workgroups as launch_frame_b256 and with 128-thread ones
+// (-DMIRO_TRACE_BLOCK=128) as launch_frame_b128 -- small frames fill the chip more evenly in the finer grain (1 to 4 spp at
+// 1080p: +4-6 %), large ones are 2 % better off with the coarser one; launch_frame (mr_internal.h) picks by sample count.
+#ifndef MR_FRAME_ENTRY
+#define MR_FRAME_ENTRY launch_frame_b256
+#endif
+mr_status MR_FRAME_ENTRY(const DeviceScene &ds, const mr_frame_desc &fd, float *d_rgb, mr_hit *d_hits, mr_hit *d_shadow_hits,
+                         unsigned long long *d_counts, hipStream_t stream) {
     FrameArgs a;
     const uint32_t spp = fd.spp;
     if (spp == 0 || spp > 64 || (spp & (spp - 1)))
