@@ -95,7 +95,8 @@ struct BounceArgs {
 // SURVEY.md section 8d, config 3), up to four.
 //
 // A workgroup takes chunks of kGenIter * kBlock rays: it first lists the rays of the chunk that have children at all (a hit
-// on a material with the wanted terms) in LDS, in ray order, then generates from the list with full waves.  Run straight
+// on a material with the wanted terms) in LDS, in ray order, counts their children, reserves the chunk's output slots with
+// one atomic, then generates from the list with full waves.  Run straight
 // over the rays the generators work at the hit rate of the queue -- the diffuse bounce rays of an open scene hit something
 // 2 % of the time, nearly every wave still holds a hit, and the launch cost what the dense first level costs.
 constexpr int kGenIter = 8;
@@ -104,6 +105,8 @@ template <bool PATH>
 __global__ __launch_bounds__(kBlock) void children_kernel(BounceArgs a) {
     __shared__ unsigned s_list[kGenIter * kBlock];            // offsets into the chunk
     __shared__ unsigned s_cnt[kGenIter][kBlock / 64];
+    __shared__ unsigned s_slot[kGenIter * kBlock];            // per listed ray: (children of earlier lanes of its wave << 3) | its own
+    __shared__ unsigned long long s_chunk_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long chunk = (unsigned long long)kBlock * kGenIter;
     const unsigned long long n_chunks = (a.n + chunk - 1) / chunk;
@@ -139,12 +142,66 @@ __global__ __launch_bounds__(kBlock) void children_kernel(BounceArgs a) {
                 s_list[at + (unsigned)__popcll(wants[it] & ((1ull << lane) - 1ull))] = (unsigned)(it * kBlock) + threadIdx.x;
         }
         __syncthreads();
-        for (unsigned j0 = 0; j0 < listed; j0 += kBlock) {                           // uniform trip count
-            ChildGen<PATH> g;
-            bool emit[4] = {false, false, false, false};
-            uint32_t pix = 0, id = 0;
-            if (j0 + threadIdx.x < listed) {
-                const unsigned long long k = base + s_list[j0 + threadIdx.x];
+        // Two passes over the list, so that the whole chunk takes ONE reservation: a single counter word drains ~88 atomics
+        // per microsecond, and one atomic per 256 listed rays (65 k for the 16.8 M rays of a bunny frame) was what the launch
+        // took -- 0.75 ms of atomics around 0.4 ms of work.
+        // pass 1: how many children each listed ray has.  Without refraction that is the material alone; a refractive hit
+        // needs its Fresnel term (the hit point is rebuilt again in pass 2 -- for those rays only).
+        const int rounds = (int)((listed + kBlock - 1) / kBlock);
+        for (int it = 0; it < kGenIter; it++) {              // (not unrolled: the generators would be inlined eight times)
+            if (it >= rounds) { if (lane == 63) s_cnt[it][wave] = 0; continue; }
+            const unsigned j = (unsigned)it * kBlock + threadIdx.x;
+            unsigned cnt = 0;
+            if (j < listed) {
+                const unsigned long long k = base + s_list[j];
+                const float4 h = reinterpret_cast<const float4 *>(a.hits)[k];
+                const uint32_t prim = __float_as_uint(h.y);
+                const float *mt = material_of(a.m, prim);
+                const bool refl = any_pos(mt + 3) && (!PATH || (a.kinds & 1u)), refr = any_pos(mt + 6) && (!PATH || (a.kinds & 2u));
+                const bool diff = PATH && any_pos(mt) && (a.kinds & 4u);
+                cnt = (refl ? 1u : 0u) + (diff ? 1u : 0u);
+                if (refr) {
+                    ChildGen<PATH> g;
+                    bool emit[4];
+                    g.mt = mt;
+                    surface_point(a.m, a.rays, k, h, g.P, g.N);
+                    const float4 rb = reinterpret_cast<const float4 *>(a.rays)[2 * k + 1];
+                    g.d[0] = rb.x; g.d[1] = rb.y; g.d[2] = rb.z;
+                    g.plan(refl, refr, diff, emit);
+                    cnt += 1u + (emit[1] ? 1u : 0u);
+                }
+            }
+            unsigned incl = cnt;
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned up = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += up;
+            }
+            if (j < listed) s_slot[j] = ((incl - cnt) << 3) | cnt;      // children of earlier lanes of my wave | my own
+            if (lane == 63) s_cnt[it][wave] = incl;          // s_cnt is free again: the list is complete
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned tot = 0;
+            for (int it = 0; it < kGenIter; it++)
+                for (int w = 0; w < kBlock / 64; w++) tot += s_cnt[it][w];
+            s_chunk_base = tot ? atomicAdd(a.out.count, (unsigned long long)tot) : 0ull;
+        }
+        __syncthreads();
+        // pass 2: generate, every ray's children next to one another
+        unsigned long long round_base = s_chunk_base;
+        for (int it = 0; it < rounds; it++) {
+            unsigned before = 0, round_total = 0;
+            for (int w = 0; w < kBlock / 64; w++) {
+                const unsigned cw = s_cnt[it][w];
+                if (w < wave) before += cw;
+                round_total += cw;
+            }
+            const unsigned j = (unsigned)it * kBlock + threadIdx.x;
+            const unsigned mine = j < listed ? s_slot[j] : 0u;
+            if (mine & 7u) {
+                const unsigned long long k = base + s_list[j];
+                ChildGen<PATH> g;
+                bool emit[4] = {false, false, false, false};
                 const float4 h = reinterpret_cast<const float4 *>(a.hits)[k];
                 const uint32_t prim = __float_as_uint(h.y);
                 g.mt = material_of(a.m, prim);
@@ -155,14 +212,16 @@ __global__ __launch_bounds__(kBlock) void children_kernel(BounceArgs a) {
                 g.d[0] = rb.x; g.d[1] = rb.y; g.d[2] = rb.z;
                 g.w0[0] = g.w0[1] = g.w0[2] = 1.f;
                 if (a.weights) { g.w0[0] = a.weights[3 * k]; g.w0[1] = a.weights[3 * k + 1]; g.w0[2] = a.weights[3 * k + 2]; }
-                pix = a.pixels ? a.pixels[k] : (uint32_t)(k / a.spp);
+                const uint32_t pix = a.pixels ? a.pixels[k] : (uint32_t)(k / a.spp);
+                uint32_t id = 0;
                 if (PATH) {
                     id = a.ids ? a.ids[k] : (uint32_t)k;
                     g.hray = pcg32(a.hbase ^ id) + a.bounce * 4u;
                 }
                 g.plan(refl, refr, diff, emit);
+                write_children_at<PATH>(a.out, g, emit, pix, id, round_base + before + (mine >> 3));
             }
-            write_children<kBlock, PATH>(a.out, g, emit, pix, id);
+            round_base += round_total;
         }
         __syncthreads();                                                             // s_list / s_cnt are reused by the next chunk
     }

@@ -340,5 +340,25 @@ __device__ __forceinline__ void write_children(const ChildQueue &q, const ChildG
     }
 }
 
+// a lane's children, one after the other from slot `s` on (the caller has reserved the slots)
+template <bool PATH>
+__device__ __forceinline__ void write_children_at(const ChildQueue &q, const ChildGen<PATH> &g, const bool emit[4], uint32_t pix,
+                                                  uint32_t id, unsigned long long s) {
+    constexpr int NK = PATH ? 4 : 3;
+#pragma unroll
+    for (int j = 0; j < NK; j++) {
+        if (emit[j]) {
+            float org[3], dir[3], wgt[3];
+            g.make(j, org, dir, wgt);
+            reinterpret_cast<float4 *>(q.rays)[2 * s] = make_float4(org[0], org[1], org[2], 0.0f);
+            reinterpret_cast<float4 *>(q.rays)[2 * s + 1] = make_float4(dir[0], dir[1], dir[2], 1e12f);
+            q.weights[3 * s] = wgt[0]; q.weights[3 * s + 1] = wgt[1]; q.weights[3 * s + 2] = wgt[2];
+            q.pixels[s] = pix;
+            if (q.ids) q.ids[s] = child_id(id, j);
+            s++;
+        }
+    }
+}
+
 }  // namespace rec
 }  // namespace mr
