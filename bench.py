@@ -185,6 +185,49 @@ def committed_pmc(workload):
     return j if j.get("per_sample") else None      # per-sample figures: scaled to the launch at hand by the caller
 
 
+def spawn_ranks(n_ranks):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1), relay their output and exit with the worst child status.
+    The parent never touches the GPU -- no HIP call, no torch.cuda.is_available() -- and never re-execs itself;
+    torch.cuda.device_count() only counts devices (it does not initialise them on this image)."""
+    import socket
+    backend = os.environ.get("MIRO_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and n_dev < n_ranks:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible -- one rank per GPU over RCCL needs %d "
+                         "(MIRO_DIST_BACKEND=gloo rehearses the control flow with ranks sharing devices)" % (n_ranks, n_dev, n_ranks))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # children inherit stdout / stderr: rank 0 prints the one JSON line itself.  A rank that dies takes the job down:
+    # the others would wait for it in a collective forever
+    worst, alive, kill_at = 0, set(range(n_ranks)), None
+    while alive:
+        for r in sorted(alive):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            alive.discard(r)
+            if rc != 0 and worst == 0:
+                worst = rc
+                sys.stderr.write("bench.py: rank %d exited with status %d; stopping the other ranks\n" % (r, rc))
+                for q in alive:
+                    procs[q].terminate()         # exact child PIDs, nothing by pattern
+                kill_at = time.monotonic() + 15.0
+        if kill_at is not None and time.monotonic() > kill_at:
+            for q in alive:
+                procs[q].kill()
+            kill_at = None
+        time.sleep(0.05)
+    raise SystemExit(worst if worst > 0 else (1 if worst else 0))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,19 +253,47 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 passes (use profiles/r02_bench_pmc.json)")
     ap.add_argument("--pmc-leg", action="store_true", help=argparse.SUPPRESS)   # internal: the profiled child
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, rendezvous, count them with an all-reduce, print {n_gpus, rccl_ranks} and stop: "
+                         "checks the launch path on a box without GPUs (with MIRO_DIST_BACKEND=gloo); renders nothing")
     a = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if a.gpus > 1:
+            spawn_ranks(a.gpus)          # never returns; nothing above this line has touched the GPU
+        world, rank, local_rank = 1, 0, 0
+    else:                                # under a launcher (torch.distributed.run) or as one of spawn_ranks' children
+        world = int(os.environ["WORLD_SIZE"])
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's rank count and --gpus must agree" % (a.gpus, world))
     # one rank per GPU over RCCL.  MIRO_DIST_BACKEND=gloo is a rehearsal switch for boxes with fewer GPUs than ranks
     # (ranks then share devices and the small collectives run on the host): never a measured configuration.
     backend = os.environ.get("MIRO_DIST_BACKEND", "nccl")
-    local_dev = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    if a.rendezvous_only:
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        if world > 1:
+            dist.init_process_group(backend, **({"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}))
+        ones = torch.ones(1, dtype=torch.float64, device=torch.device("cuda", local_rank) if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(ones)
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "rccl_ranks": int(ones.item()) if backend == "nccl" or world == 1 else 0,
+                              "ranks_counted": int(ones.item()), "dist_backend": backend if world > 1 else None, "rendezvous_only": True}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1 or not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if backend == "nccl" and local_rank >= n_dev:
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible -- refusing to wrap devices" % (rank, local_rank, n_dev))
+    local_dev = local_rank % n_dev if backend != "nccl" else local_rank
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     red_dev = dev if backend == "nccl" else torch.device("cpu")
@@ -350,8 +421,14 @@ def main():
         tmax = tot[1:2].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         rays_per_step, elapsed = float(rays_all.item()), float(tmax.item())
+        ones = torch.ones(1, dtype=torch.float64, device=red_dev)       # every rank that took part adds one
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(ones.item())))
+        if ranks_seen != dist.get_world_size() or ranks_seen != a.gpus:
+            raise SystemExit("rank %d: %d ranks answered the all-reduce, --gpus %d" % (rank, ranks_seen, a.gpus))
     else:
         rays_per_step = float(n_p + n_s)
+        ranks_seen = 1
 
     if rank == 0:
         workload = "%s %dx%d %dspp primary+shadow" % (label, W, H, spp)
@@ -441,6 +518,8 @@ def main():
             "value": round(rays_per_step * a.steps / elapsed / 1e6, 2),
             "unit": "Mrays/s",
             "n_gpus": world,
+            "rccl_ranks": ranks_seen if backend == "nccl" or world == 1 else 0,     # 0: a gloo rehearsal, not RCCL
+            "dist_backend": backend if world > 1 else None,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4),

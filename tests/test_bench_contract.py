@@ -22,7 +22,7 @@ def test_bench_prints_one_contract_line():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in j, k
-    assert j["unit"] == "Mrays/s" and j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1
+    assert j["unit"] == "Mrays/s" and j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["rccl_ranks"] == 1
     assert j["higher_is_better"] is True and j["scaling"] == "strong" and j["vs_baseline"] is None and j["dtype"] == "f32"
     assert j["value"] > 0 and j["ms_per_step"] > 0
     assert "workload" in j["config"] and "model" not in j["config"]
@@ -63,14 +63,11 @@ def test_bench_two_ranks_rehearsal():
     """The N > 1 flow of bench.py -- rendezvous, interleaved row bands, per-rank frames, the pipelined framebuffer gather,
     max-over-ranks timing, one line from rank 0 -- with two ranks sharing this box's GPU.  The collectives run over gloo
     here (MIRO_DIST_BACKEND, host-staged gather): a rehearsal of the control flow, not a measurement."""
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ, MIRO_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    # the plain command, no launcher: bench.py starts its two ranks itself (before anything touches the GPU)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "320", "--height", "184", "--spp", "4"],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
@@ -78,5 +75,41 @@ def test_bench_two_ranks_rehearsal():
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0
+    assert j["dist_backend"] == "gloo" and j["rccl_ranks"] == 0       # a rehearsal says so: no RCCL rank took part
     assert j["config"]["rays_per_step"] >= 320 * 184 * 4          # both ranks' rays are counted
     assert "cpu_baseline" not in j                                # rank 0 times the CPU only at N = 1
+
+
+def _plain_env(**extra):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra)
+    return env
+
+
+def test_bench_gpus_n_starts_n_ranks_without_a_launcher():
+    """`python bench.py --gpus N` with WORLD_SIZE unset must run N ranks, never one.  No GPU here, so the
+    ranks only rendezvous (gloo) and count themselves with an all-reduce."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--rendezvous-only"],
+                       capture_output=True, text=True, timeout=300, env=_plain_env(MIRO_DIST_BACKEND="gloo"))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 3 and j["ranks_counted"] == 3 and j["dist_backend"] == "gloo"
+
+
+def test_bench_gpus_n_refuses_to_measure_fewer_gpus():
+    """With the RCCL backend (the measured configuration) and fewer visible GPUs than --gpus the command fails loudly
+    instead of wrapping devices or silently printing n_gpus: 1; and a launcher whose rank count disagrees with --gpus is
+    an error too."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=_plain_env(MIRO_DIST_BACKEND="nccl"))
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "GPU(s) visible" in r.stderr, (r.stdout + r.stderr)[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{") and json.loads(l).get("n_gpus") == 1], r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--rendezvous-only"],
+                       capture_output=True, text=True, timeout=300, env=_plain_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "must agree" in r.stderr, (r.stdout + r.stderr)[-2000:]

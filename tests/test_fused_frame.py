@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import product_scene
+from helpers import camera_of, oracle_scene, product_scene
 from miro_amd import binding
 from miro_amd import frame as mframe
 from miro_amd import scenes
@@ -156,3 +156,51 @@ def test_fused_frame_full_size_properties(miro, spp):
     ref.step()
     torch.cuda.synchronize()
     assert torch.equal(ref.d_rgb.view(torch.int32), fu.d_rgb.view(torch.int32))
+
+
+def test_bench_frame_window_against_the_oracle(oracle, miro):
+    """The timed kernel at its own configuration, directly against the oracle: rows 536-540 of the
+    bench frame -- sponza 1920x1080, 64 jittered samples per pixel, frame_kernel<794,false> in 256-lane workgroups is what
+    bench.py times -- primary and shadow mr_hit records bytes-equal to the oracle's Scene::trace on the oracle's own eye and
+    shadow rays (Camera.cpp:104-161, Phong.cpp:80-97), pixels within 1e-5 of the restated Phong::shade (Phong.cpp:116-156)."""
+    name, W, H, spp, y0, y1 = "sponza", 1920, 1080, 64, 536, 540
+    d = scenes.SCENES[name]
+    sc, ref = product_scene(miro, name), oracle_scene(oracle, name)
+    n = (y1 - y0) * W * spp
+    f32 = dict(dtype=torch.float32, device="cuda")
+    d_rgb = torch.zeros(((y1 - y0) * W, 3), **f32)
+    d_h, d_s = torch.empty((n, 4), **f32), torch.empty((n, 4), **f32)
+    d_counts = torch.zeros(2, dtype=torch.int64, device="cuda")
+    # a window this size (491 520 samples) would be launched in 128-lane workgroups; the bench frame runs the 256-lane
+    # build, so render the window as the bench does: through the whole-frame launch of a renderer that keeps its hits
+    full = mframe.FusedFrame(sc, d, W, H, spp=spp, jitter=True, seed=168, tiled=False, keep_hits=True)
+    full.step()
+    torch.cuda.synchronize()
+    lo, hi = y0 * W * spp, y1 * W * spp
+    got_h = full.d_hits[lo:hi].cpu().numpy().view(miro.HIT_DTYPE).reshape(-1)
+    got_s = full.d_shadow_hits[lo:hi].cpu().numpy().view(miro.HIT_DTYPE).reshape(-1)
+    got_rgb = full.d_rgb[y0 * W:y1 * W].cpu().numpy()
+    # ... and the same rows as a window of their own (the 128-lane build): the same bytes
+    sc.render_direct(full.cam, W, H, d_rgb, d["light"], d["wattage"], y0=y0, y1=y1, spp=spp, jitter=True, seed=168, tiled=False,
+                     d_hits=d_h, d_shadow_hits=d_s, d_counts=d_counts)
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits(d_h), _bits(full.d_hits[lo:hi])) and np.array_equal(_bits(d_s), _bits(full.d_shadow_hits[lo:hi]))
+    assert np.array_equal(_bits(d_rgb), _bits(full.d_rgb[y0 * W:y1 * W]))
+    del full
+    torch.cuda.empty_cache()
+
+    rays = oracle.eye_rays(camera_of(oracle, name), W, H, spp=spp, jitter=True, seed=168, y0=y0, y1=y1)
+    want = ref.trace(rays)
+    assert got_h.tobytes() == want.tobytes(), "primary hit records differ from the oracle's"
+    sh, src = ref.shadow_rays(rays, want, d["light"])
+    want_s = ref.trace(sh)
+    src = src.astype(np.int64)
+    assert got_s[src].tobytes() == want_s.tobytes(), "shadow hit records differ from the oracle's"
+    rest = np.ones(n, bool)
+    rest[src] = False
+    assert (got_s["prim"][rest] == oracle.MISS).all() and (got_s["t"][rest] == 0).all()
+    assert d_counts.cpu().numpy().tolist() == [n, len(sh)]
+    occ = np.zeros(n, np.uint8)
+    occ[src] = want_s["prim"] != oracle.MISS
+    want_rgb = ref.shade_direct(rays, want, occ, d["light"], d["wattage"], spp=spp)
+    assert want_rgb.max() > 0 and np.abs(got_rgb - want_rgb).max() <= 1e-5 * max(1.0, np.abs(want_rgb).max())
