@@ -44,7 +44,9 @@ HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 N_SIMD = 1024                # 256 CUs x 4 SIMD-32
 CLOCK_GHZ = 2.4              # MI355X_MICROARCH.md: peak engine clock
 VALU_PEAK_GINSTR = N_SIMD * CLOCK_GHZ / 2.0    # a wave64 VALU instruction holds its SIMD-32 for 2 cycles (guide, line 54/473)
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_bench_pmc.json")
+ROUND_TAG = "r03"
+PMC_FILE = next((f for f in (os.path.join(ROOT, "profiles", "%s_bench_pmc.json" % t) for t in (ROUND_TAG, "r02")) if os.path.exists(f)),
+                os.path.join(ROOT, "profiles", "r02_bench_pmc.json"))
 SQ_COUNTERS = "SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY"
 
 
@@ -245,13 +247,15 @@ def main():
                          "differ from the reference's on 2-ulp ties)")
     ap.add_argument("--incoherent", action="store_true", help="MR_TRACE_INCOHERENT: the voting control flow")
     ap.add_argument("--any-shadow", action="store_true", help="any-hit shadow rays (opaque scenes only)")
+    ap.add_argument("--mode", choices=["primary+shadow", "primary"], default="primary+shadow",
+                    help="primary: no shadow rays, the reference's -DDISABLE_SHADOWS build (BASELINE config 2 is 'primary rays only')")
     ap.add_argument("--batched", action="store_true",
                     help="the round-1 pipeline: resident ray buffers, five kernels per step (eye rays generated once, outside "
                          "the step)")
     ap.add_argument("--image-order", action="store_true", help="samples in image order instead of the tiled order (< 64 spp)")
     ap.add_argument("--cpu-spp", type=int, default=8, help="samples per pixel of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 passes (use profiles/r02_bench_pmc.json)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 passes (use the committed profiles/rNN_bench_pmc.json)")
     ap.add_argument("--pmc-leg", action="store_true", help=argparse.SUPPRESS)   # internal: the profiled child
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, rendezvous, count them with an all-reduce, print {n_gpus, rccl_ranks} and stop: "
@@ -323,6 +327,9 @@ def main():
     flags = (miro_amd.MR_MATH_PRODUCT if a.product else 0) | (miro_amd.MR_TRACE_INCOHERENT if a.incoherent else 0)
     stream = torch.cuda.current_stream()
     fused = not a.batched and spp <= 64 and spp & (spp - 1) == 0
+    primary_only = a.mode == "primary"
+    if primary_only and (not fused or a.product or a.incoherent or a.any_shadow):
+        raise SystemExit("--mode primary runs the fused step with the default traversal (no --batched / --product / --incoherent / --any-shadow)")
     tiled = not a.image_order and spp < 64
 
     # multi-GPU: two send buffers, used by alternate frames, so that frame k's gather (asynchronous, RCCL's own stream)
@@ -331,7 +338,7 @@ def main():
     if fused:
         frs = [mframe.FusedFrame(scene, desc, W, H, spp=spp, band=a.band, rank=rank, world=world, jitter=spp > 1, seed=168,
                                  flags=flags, rgb=g.local if g is not None and len(bands) else None, tiled=tiled,
-                                 any_shadow=a.any_shadow) for g in (gathers or [None])]
+                                 any_shadow=a.any_shadow, no_shadows=primary_only) for g in (gathers or [None])]
     else:
         frs = [mframe.FrameRenderer(scene, desc, W, H, spp=spp, bands=bands, jitter=spp > 1, seed=168, flags=flags,
                                     rgb=g.local if g is not None and len(bands) else None, tiled=tiled)
@@ -431,7 +438,7 @@ def main():
         ranks_seen = 1
 
     if rank == 0:
-        workload = "%s %dx%d %dspp primary+shadow" % (label, W, H, spp)
+        workload = "%s %dx%d %dspp %s" % (label, W, H, spp, a.mode)
         # ---- dominant kernel: live HIP-event durations of its launches on rank 0's stream
         if fused:
             ms_k = [e[0].elapsed_time(e[1]) for e in events]
@@ -453,7 +460,7 @@ def main():
             leg = ["--pmc-leg", "--no-cpu-baseline", "--no-pmc", "--scene", a.scene, "--width", str(W), "--height", str(H),
                    "--spp", str(spp), "--steps", "2", "--warmup", "1"] + (["--product"] if a.product else []) + \
                   (["--incoherent"] if a.incoherent else []) + (["--any-shadow"] if a.any_shadow else []) + \
-                  (["--image-order"] if a.image_order else [])
+                  (["--image-order"] if a.image_order else []) + ["--mode", a.mode]
             pmc, pmc_note = live_pmc(leg, "frame_kernel")
             if pmc:
                 pmc_source = "live: rocprofv3 --pmc passes over this workload, started by this run"
@@ -463,8 +470,8 @@ def main():
                        "flags": {"product": a.product, "incoherent": a.incoherent, "any_shadow": a.any_shadow, "tiled": tiled}}
                 try:
                     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-                    default_frame = (a.scene, W, H, spp) == ("sponza", 1920, 1080, 64) and not (a.product or a.incoherent or a.any_shadow)
-                    name = "r02_bench_pmc.json" if default_frame else "r02_bench_pmc_%s_%dx%d_%dspp.json" % (a.scene, W, H, spp)
+                    default_frame = (a.scene, W, H, spp) == ("sponza", 1920, 1080, 64) and not (a.product or a.incoherent or a.any_shadow or primary_only)
+                    name = "%s_bench_pmc.json" % ROUND_TAG if default_frame else "%s_bench_pmc_%s_%dx%d_%dspp.json" % (ROUND_TAG, a.scene, W, H, spp)
                     json.dump(rec, open(os.path.join(ROOT, "gpurun_out", name), "w"), indent=1)
                 except Exception:
                     pass
@@ -472,7 +479,7 @@ def main():
             rec = committed_pmc(workload)
             if rec:
                 pmc = {k: v * samples_rank0 for k, v in rec["per_sample"].items()}
-                pmc_source = "committed: profiles/r02_bench_pmc.json (%s), scaled per sample to this launch" % rec.get("workload")
+                pmc_source = "committed: profiles/%s (%s), scaled per sample to this launch" % (os.path.basename(PMC_FILE), rec.get("workload"))
         roof = {"bound": "valu_issue", "kernel": kernel_name, "peak": round(VALU_PEAK_GINSTR, 1), "unit": "Ginstr/s",
                 "peak_definition": "%d SIMD-32 x %.1f GHz / 2 cycles per wave64 VALU instruction" % (N_SIMD, CLOCK_GHZ),
                 "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step, "pmc_source": pmc_source}
@@ -514,7 +521,7 @@ def main():
             "hbm_measured_frac": round(traffic / kernel_s_per_step / 1e9 / HBM_PEAK_GBPS, 4) if traffic is not None else None,
         }
         out = {
-            "metric": "Mrays/s (primary+shadow)",
+            "metric": "Mrays/s (%s)" % a.mode,
             "value": round(rays_per_step * a.steps / elapsed / 1e6, 2),
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -538,7 +545,7 @@ def main():
                 "math": "exact triangle test, slab distances as products with the rounded 1/d (MR_MATH_PRODUCT)" if a.product else
                         "exact: every quotient of the reference's slab and triangle tests, bit for bit",
                 "control_flow": "voting (MR_TRACE_INCOHERENT)" if a.incoherent else "while-while",
-                "shadow_query": "any-hit" if a.any_shadow else "closest-hit (as Phong.cpp:97)",
+                "shadow_query": "none (-DDISABLE_SHADOWS, Phong.cpp:91)" if primary_only else ("any-hit" if a.any_shadow else "closest-hit (as Phong.cpp:97)"),
                 "ray_order": "tiled" if (fr0.tiled if hasattr(fr0, "tiled") else False) else "image order",
                 "parallelism": "image rows in interleaved bands of %d over %d GPU(s), scene replicated, 1 RCCL gather of the framebuffer" % (a.band, world),
                 "resident_bytes_per_gpu": int(sum(fr.bytes_resident() for fr in (frs if fused else frs[:1])) + info.device_bytes),

@@ -188,6 +188,10 @@ mr_status upload_materials(mr_scene *s) {
                                   "again after the last object was added", s->prim_material.size(), s->mesh.n_triangles());
     (void)hipFree(d.materials); (void)hipFree(d.prim_material);
     d.materials = nullptr; d.prim_material = nullptr;
+    d.user_materials = s->materials.empty() ? 0u : 1u;
+    d.refractive = 0;
+    for (size_t i = 0; i + 10 < s->materials.size(); i += 11)
+        if (s->materials[i + 6] > 0.f || s->materials[i + 7] > 0.f || s->materials[i + 8] > 0.f) d.refractive = 1;
     static const float white[11] = {1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1};
     const float *src = s->materials.empty() ? white : s->materials.data();
     const size_t nfl = s->materials.empty() ? 11 : s->materials.size();
@@ -591,6 +595,12 @@ mr_status mr_shade_direct(mr_scene *s, const mr_ray *d_rays, const mr_hit *d_hit
     if (!d_rays || !d_hits || !d_shadow_hits || !d_shadow_src || !d_shadow_count || !light || !diffuse || !d_rgb)
         return fail(MR_ERR_INVALID, "NULL argument");
     if (spp == 0 || n % spp != 0) return fail(MR_ERR_INVALID, "n (%llu) must be a multiple of spp (%u)", (unsigned long long)n, spp);
+    // this call shades a uniform material and knows occluders as a flag per ray (opaque occluders, see the header): in a
+    // scene with a refractive material the light behind such an occluder is attenuated, not removed (Phong.cpp:99-113) --
+    // mr_shade_accumulate (batched) and mr_render_direct / mr_trace_level (one launch) implement that
+    if (s->dev.refractive)
+        return fail(MR_ERR_STATE, "mr_shade_direct: the scene has a refractive material; use mr_shade_accumulate, mr_render_direct "
+                                  "or mr_trace_level, which let light through refractive occluders as Phong.cpp:99-113 does");
     MR_HIP_CHECK(hipSetDevice(s->device));
     if (n > s->occluded_cap) {     // grow-only scratch; size it with a first call outside any graph capture
         (void)hipFree(s->d_occluded);

@@ -18,6 +18,7 @@
 #include "mr_eye.h"
 #include "mr_internal.h"
 #include "mr_phong.h"
+#include "mr_recursion.h"
 #include "mr_surface.h"
 #include "mr_tile.h"
 #include "mr_traverse.h"
@@ -30,15 +31,22 @@ struct FrameArgs {
     TraceParams tp;              // scene arrays, root box; rays / hits / n unused
     SurfacePtrs m;
     DirectLight lt;
+    const float *mats;           // MAT kernels: the scene's material table (11 floats each) and the material of every object
+    const uint32_t *prim_mat;
     mr_hit *hits;                // optional: primary hit record of sample k
     mr_hit *shadow_hits;         // optional: record of sample k's shadow ray (prim = MR_MISS, t = 0 when it has none)
     float *rgb;                  // [rows * W][3], window rows in band order, image order inside a row
     unsigned long long *counts;  // optional: [0] += primary rays, [1] += shadow rays traced by this launch
 };
 
-// VAR: the traversal variant of trace_ray (mr_traverse.h) for both rays; ANY_SHADOW: the shadow ray stops at its first
-// accepted hit (opaque scenes: same occlusion flag, hence the same picture).
-template <int VAR, bool ANY_SHADOW>
+// VAR: the traversal variant of trace_ray (mr_traverse.h) for both rays.
+// SHADOW: 0 = the shadow ray is a closest-hit query as Phong.cpp:97; 1 = it stops at its first accepted hit (opaque scenes:
+// same occlusion flag, hence the same picture); 2 = no shadow ray at all -- the reference's -DDISABLE_SHADOWS build
+// (Phong.cpp:91), BASELINE config 2's "primary rays only".
+// MAT: Phong::shade with the scene's per-object materials (mr_scene_set_materials) instead of the frame's uniform one:
+// diffuse term and highlight from the hit's material (Phong.cpp:116-156) and light through a refractive occluder scaled by
+// dot(N, l) of the occluder (Phong.cpp:99-113) -- the pieces of mr_recursion.h that mr_trace_level shades with.
+template <int VAR, int SHADOW, bool MAT>
 __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(7, 8))) void frame_kernel(FrameArgs a) {
     extern __shared__ int s_stack[];                  // [stack_depth][kTraceBlock]
     __shared__ unsigned s_shadow_rays[kTraceBlock / 64];
@@ -75,31 +83,51 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(7, 
         // ---- shadow ray from the hit in registers (Phong.cpp:80-97).  The sample's colour is computed BEFORE the
         // shadow ray is traced and zeroed afterwards if the light is occluded (Phong.cpp:97-100): only three values
         // stay live across the second traversal instead of the hit point, the normal and the eye direction, which
-        // keeps the kernel at the register count of the plain trace kernel.
+        // keeps the kernel at the register count of the plain trace kernel.  (MAT: four -- the highlight apart, because a
+        // refractive occluder scales the diffuse term only, Phong.cpp:146.)
         const bool hit = live && h.prim != MR_MISS;
-        float c[3] = {0.f, 0.f, 0.f};
+        float c[3] = {0.f, 0.f, 0.f}, highlight = 0.0f;
         if (live && !hit) { c[0] = a.lt.bg[0]; c[1] = a.lt.bg[1]; c[2] = a.lt.bg[2]; }         // Scene.cpp:340
         float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = make_float4(1.f, 1.f, 1.f, -1.f);
         if (hit) {
             float P[3], N[3];
-            surface_od<true>(a.m, ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, h.t, h.prim, h.beta, h.gamma, P, N);
-            shadow_ray_of(P, a.lt.L[0], a.lt.L[1], a.lt.L[2], sa, sb);
-            phong_direct(a.lt, P, N, rb.x, rb.y, rb.z, c);                                      // Phong.cpp:116-156
-            my_shadow_rays++;
+            if (MAT) {
+                rec::MeshMat mm;
+                mm.s = a.m; mm.mats = a.mats; mm.prim_mat = a.prim_mat;
+                rec::LightArgs la;
+                for (int k = 0; k < 3; k++) { la.L[k] = a.lt.L[k]; la.color[k] = a.lt.color[k]; }
+                la.wattage = a.lt.wattage;
+                rec::surface_point_od(mm, ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, h.t, h.prim, h.beta, h.gamma, P, N);
+                rec::phong_terms(la, rec::material_of(mm, h.prim), P, N, rb.x, rb.y, rb.z, c, highlight);
+            } else {
+                surface_od<true>(a.m, ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, h.t, h.prim, h.beta, h.gamma, P, N);
+            }
+            if (SHADOW != 2) shadow_ray_of(P, a.lt.L[0], a.lt.L[1], a.lt.L[2], sa, sb);
+            if (!MAT) phong_direct(a.lt, P, N, rb.x, rb.y, rb.z, c);                            // Phong.cpp:116-156
+            if (SHADOW != 2) my_shadow_rays++;
         }
-        bool occluded;
-        {
+        if (SHADOW != 2) {
             RayRegs r;
             ray_setup(r, sa, sb);
             Lane L;
             int plane_hit;
-            trace_ray<true, ANY_SHADOW, false, VAR>(a.tp, r, sb.w, hit, L, plane_hit, s_stack, tid, st);
+            trace_ray<true, SHADOW == 1, false, VAR>(a.tp, r, sb.w, hit, L, plane_hit, s_stack, tid, st);
             mr_hit hs = make_hit<kObj>(a.tp, L, plane_hit, sb.w);
             if (!hit) { hs.t = 0.0f; hs.prim = MR_MISS; hs.beta = 0.0f; hs.gamma = 0.0f; }
-            occluded = hs.prim != MR_MISS;
             if (a.shadow_hits && live) reinterpret_cast<float4 *>(a.shadow_hits)[idx] = *reinterpret_cast<const float4 *>(&hs);
+            if (MAT) {
+                if (hit) {
+                    rec::MeshMat mm;
+                    mm.s = a.m; mm.mats = a.mats; mm.prim_mat = a.prim_mat;
+                    rec::phong_combine(c, highlight, rec::light_scale_of(mm, sa, sb, *reinterpret_cast<const float4 *>(&hs)), c);
+                }
+            } else if (hs.prim != MR_MISS) {
+                c[0] = 0.f; c[1] = 0.f; c[2] = 0.f;
+            }
+        } else {
+            if (a.shadow_hits && live) reinterpret_cast<float4 *>(a.shadow_hits)[idx] = make_float4(0.0f, __uint_as_float(MR_MISS), 0.0f, 0.0f);
+            if (MAT && hit) rec::phong_combine(c, highlight, 1.0f, c);
         }
-        if (occluded) { c[0] = 0.f; c[1] = 0.f; c[2] = 0.f; }
         // the pixel's mean (Scene.cpp:126-139)
         // spp is a power of two <= 64 (checked by the host): a pixel's samples are `spp` consecutive, aligned lanes; the
         // summation tree depends on the sample index only -- the same tree as shade_samples_kernel's
@@ -133,18 +161,31 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(7, 
     }
 }
 
-template <int VAR, bool ANY_SHADOW>
+template <int VAR, int SHADOW, bool MAT>
 mr_status launch_frame_t(const FrameArgs &a, hipStream_t stream) {
     const size_t lds = (size_t)a.tp.stack_depth * kTraceBlock * sizeof(int);
     if (lds > 150 * 1024) return fail(MR_ERR_INVALID, "traversal stack of depth %d does not fit in LDS", a.tp.stack_depth);
     if (lds > 48 * 1024)
-        MR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&frame_kernel<VAR, ANY_SHADOW>),
+        MR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&frame_kernel<VAR, SHADOW, MAT>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     unsigned long long blocks = (a.eye.n + kTraceBlock - 1) / kTraceBlock;
     if (blocks > (unsigned long long)kTraceGridCap) blocks = kTraceGridCap;
-    hipLaunchKernelGGL((frame_kernel<VAR, ANY_SHADOW>), dim3((unsigned)blocks), dim3(kTraceBlock), lds, stream, a);
+    hipLaunchKernelGGL((frame_kernel<VAR, SHADOW, MAT>), dim3((unsigned)blocks), dim3(kTraceBlock), lds, stream, a);
     MR_HIP_CHECK(hipGetLastError());
     return MR_OK;
+}
+
+// the uniform-material frame: closest-hit or any-hit shadow rays in every traversal mode
+template <int VAR>
+mr_status launch_frame_plain(const FrameArgs &a, bool any, hipStream_t stream) {
+    return any ? launch_frame_t<VAR, 1, false>(a, stream) : launch_frame_t<VAR, 0, false>(a, stream);
+}
+// the default (exact) traversal also comes without shadow rays (-DDISABLE_SHADOWS) and with per-object materials
+template <int VAR>
+mr_status launch_frame_default(const FrameArgs &a, bool any, bool no_shadows, bool mat, hipStream_t stream) {
+    if (mat) return no_shadows ? launch_frame_t<VAR, 2, true>(a, stream) : launch_frame_t<VAR, 0, true>(a, stream);
+    if (no_shadows) return launch_frame_t<VAR, 2, false>(a, stream);
+    return launch_frame_plain<VAR>(a, any, stream);
 }
 
 }  // namespace
@@ -201,19 +242,23 @@ mr_status MR_FRAME_ENTRY(const DeviceScene &ds, const mr_frame_desc &fd, float *
     a.lt.wattage = fd.light.wattage;
     a.hits = d_hits; a.shadow_hits = d_shadow_hits; a.rgb = d_rgb; a.counts = d_counts;
 
+    a.mats = ds.materials; a.prim_mat = ds.prim_material;
     const bool any = fd.flags & MR_TRACE_ANY, product = fd.flags & MR_MATH_PRODUCT, vote = fd.flags & MR_TRACE_INCOHERENT;
-    if (fd.flags & ~(uint32_t)(MR_TRACE_ANY | MR_MATH_PRODUCT | MR_TRACE_INCOHERENT))
-        return fail(MR_ERR_INVALID, "mr_render_direct: flags may hold MR_TRACE_ANY, MR_MATH_PRODUCT, MR_TRACE_INCOHERENT only");
-    if (ds.n_planes || ds.n_spheres) {
-        if (product) return any ? launch_frame_t<43, true>(a, stream) : launch_frame_t<43, false>(a, stream);
-        return any ? launch_frame_t<826, true>(a, stream) : launch_frame_t<826, false>(a, stream);
-    }
-    if (vote) {
-        if (product) return any ? launch_frame_t<73, true>(a, stream) : launch_frame_t<73, false>(a, stream);
-        return any ? launch_frame_t<88, true>(a, stream) : launch_frame_t<88, false>(a, stream);
-    }
-    if (product) return any ? launch_frame_t<267, true>(a, stream) : launch_frame_t<267, false>(a, stream);
-    return any ? launch_frame_t<794, true>(a, stream) : launch_frame_t<794, false>(a, stream);
+    const bool no_shadows = fd.flags & MR_FRAME_NO_SHADOWS, mat = ds.user_materials != 0;
+    if (fd.flags & ~(uint32_t)(MR_TRACE_ANY | MR_MATH_PRODUCT | MR_TRACE_INCOHERENT | MR_FRAME_NO_SHADOWS))
+        return fail(MR_ERR_INVALID, "mr_render_direct: flags may hold MR_TRACE_ANY, MR_MATH_PRODUCT, MR_TRACE_INCOHERENT, MR_FRAME_NO_SHADOWS only");
+    if (any && no_shadows) return fail(MR_ERR_INVALID, "mr_render_direct: MR_TRACE_ANY and MR_FRAME_NO_SHADOWS exclude one another");
+    if (any && ds.refractive)
+        return fail(MR_ERR_STATE, "mr_render_direct: MR_TRACE_ANY in a scene with a refractive material -- the light through such an "
+                                  "occluder depends on WHICH occluder is nearest (Phong.cpp:99-113)");
+    if ((mat || no_shadows) && (product || vote || (mat && any)))
+        return fail(MR_ERR_INVALID, "mr_render_direct: per-object materials and MR_FRAME_NO_SHADOWS come with the default traversal only "
+                                    "(no MR_MATH_PRODUCT / MR_TRACE_INCOHERENT%s)", mat ? " / MR_TRACE_ANY" : "");
+    if (ds.n_planes || ds.n_spheres)
+        return product ? launch_frame_plain<43>(a, any, stream) : launch_frame_default<826>(a, any, no_shadows, mat, stream);
+    if (vote) return product ? launch_frame_plain<73>(a, any, stream) : launch_frame_plain<88>(a, any, stream);
+    if (product) return launch_frame_plain<267>(a, any, stream);
+    return launch_frame_default<794>(a, any, no_shadows, mat, stream);
 }
 
 }  // namespace mr

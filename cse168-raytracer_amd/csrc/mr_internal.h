@@ -99,6 +99,8 @@ struct DeviceScene {
     // every triangle; prim_material == nullptr means material 0 everywhere
     float    *materials = nullptr;
     uint32_t *prim_material = nullptr;
+    uint32_t user_materials = 0;       // mr_scene_set_materials was called (otherwise `materials` is the one white Lambert)
+    uint32_t refractive = 0;           // some material has a positive transmission component (Phong::isRefractive)
     float4   *spheres = nullptr;       // (c.xyz, radius) per sphere; nullptr when the scene has none
     float4   *planes = nullptr;        // 2 per plane; nullptr when the scene has none
     uint32_t n_spheres = 0, n_planes = 0;

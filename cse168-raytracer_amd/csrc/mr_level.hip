@@ -53,8 +53,11 @@ struct LevelArgs {
 // their occupancy.  The path-tracing form gets 96 (5 waves): its double arithmetic also keeps ~280 constants' worth of
 // SGPRs spilled into VGPR lanes, and with 77-94 spilled VGPRs on top of that under an 80-register cap a build of this
 // kernel faulted on the GPU; at 96 it spills <= 18 (tests/test_build_budget.py keeps every kernel below 48).
+#ifndef MIRO_LEVEL_PATH_WAVES
+#define MIRO_LEVEL_PATH_WAVES 5
+#endif
 template <int VAR, int CHILDREN>
-__global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(CHILDREN == 2 ? 5 : 6, 8))) void level_kernel(LevelArgs a) {
+__global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(CHILDREN == 2 ? MIRO_LEVEL_PATH_WAVES : 6, 8))) void level_kernel(LevelArgs a) {
     extern __shared__ int s_stack[];                  // [stack_depth][kTraceBlock]
     __shared__ unsigned s_shadow_rays[kTraceBlock / 64];
     const int tid = threadIdx.x;

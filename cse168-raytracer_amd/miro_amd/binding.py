@@ -23,6 +23,7 @@ MR_COUNT_STATS = 1 << 4
 MR_TRACE_PERSISTENT = 1 << 5
 MR_MATH_PRODUCT = 1 << 6
 MR_TRACE_INCOHERENT = 1 << 7
+MR_FRAME_NO_SHADOWS = 1 << 8
 
 MR_PATH_MIRROR, MR_PATH_REFRACT, MR_PATH_DIFFUSE = 1, 2, 4
 MR_LEVEL_LAST, MR_LEVEL_SPECULAR, MR_LEVEL_PATH = 0, 1, 2
@@ -115,7 +116,7 @@ def load_library(path=None):
     """Load libmiro_hip.so, compiling it first if it is not there; raises if that fails (there is no fallback:
     without the HIP library nothing in this package computes anything)."""
     global _lib
-    path = path or _LIB
+    path = path or os.environ.get("MIRO_LIB") or _LIB       # MIRO_LIB: an A/B build of the library (Makefile VARIANT=...)
     if not os.path.exists(path) and path == _LIB:
         build_library()
     if not os.path.exists(path):

@@ -125,13 +125,15 @@ class FusedFrame:
     (16 + 16 B per sample) that parity tests compare with the batched pipeline's."""
 
     def __init__(self, scene, desc, W, H, spp=1, band=None, rank=0, world=1, jitter=None, seed=168, flags=0, rgb=None,
-                 tiled=None, keep_hits=False, any_shadow=False):
+                 tiled=None, keep_hits=False, any_shadow=False, no_shadows=False):
+        """no_shadows: MR_FRAME_NO_SHADOWS, the reference's -DDISABLE_SHADOWS build (primary rays only, BASELINE config 2).
+        A scene with a material table (Scene.set_materials) is shaded with its per-object materials (Phong.cpp:99-156)."""
         if isinstance(desc, str):
             desc = scenes.SCENES[desc]
         self.scene, self.desc, self.W, self.H, self.spp = scene, desc, W, H, spp
         self.jitter = (spp > 1) if jitter is None else jitter
         self.seed = seed
-        self.flags = flags | (binding.MR_TRACE_ANY if any_shadow else 0)
+        self.flags = flags | (binding.MR_TRACE_ANY if any_shadow else 0) | (binding.MR_FRAME_NO_SHADOWS if no_shadows else 0)
         self.device = torch.device("cuda", scene.device)
         self.bands = (band, rank, world) if world > 1 else None
         self.n_rows = sum(y1 - y0 for y0, y1 in band_rows(H, band, rank, world)) if world > 1 else H

@@ -106,6 +106,9 @@ enum {
                                       steps in the same order: identical hit records.  Combines with MR_TRACE_PERSISTENT.
                                       Without the hint the default kernel decides per wave: a wave whose rays point into
                                       several octants votes, one whose rays share an octant does not */
+    MR_FRAME_NO_SHADOWS = 1u << 8, /* mr_render_direct only: the reference's -DDISABLE_SHADOWS build (Phong.cpp:91) -- no shadow ray
+                                      is built or traced, every light reaches every hit (BASELINE config 2, "primary rays
+                                      only"); default traversal only */
     MR_MATH_PRODUCT   = 1u << 6    /* slab distances as products (corner - o) * RN(1/d) instead of the reference's
                                       quotients (corner - o) / d (BVH.cpp:601-602), whose decisions the default reproduces
                                       exactly (products where the visit's comparisons are more than 16 ulp from a tie --
@@ -215,7 +218,8 @@ typedef struct mr_light {                             /* PointLight.h:8-59 */
 } mr_light;
 /* For n primary rays (spp consecutive rays per pixel) with their hits, and the traced shadow batch of
  * mr_gen_shadow_rays (hits + source indices + device count): direct lighting of a uniform material with
- * diffuse colour `diffuse` as Phong::shade computes it (Phong.cpp:44-160; opaque occluders), normals
+ * diffuse colour `diffuse` as Phong::shade computes it (Phong.cpp:44-160; opaque occluders only: MR_ERR_STATE when the
+ * scene's material table holds a refractive material -- mr_shade_accumulate handles those), normals
  * normalised as Scene::trace does (Scene.cpp:262), misses = background 0 (Scene.cpp:340,685), averaged over
  * the spp samples of each pixel (Scene.cpp:126-139) into d_rgb[(n/spp)*3] -- the linear float framebuffer
  * (tempImage, Scene.cpp:106).  All pointers are device pointers. */
@@ -232,7 +236,12 @@ mr_status mr_shade_direct(mr_scene *scene, const mr_ray *d_rays, const mr_hit *d
  * (bands of band_rows rows dealt round-robin: rank r owns bands r, r + band_world, ...; y0/y1 ignored).
  * spp: a power of two <= 64 (other counts: use the batched calls).  tiled: sample order of mr_gen_eye_rays_tiled over
  * the window's rows (sample k of d_hits / d_shadow_hits follows that order); d_rgb is always in image order.
- * flags: MR_MATH_PRODUCT, MR_TRACE_INCOHERENT (both rays), MR_TRACE_ANY (shadow ray only). */
+ * flags: MR_MATH_PRODUCT, MR_TRACE_INCOHERENT (both rays), MR_TRACE_ANY (shadow ray only), MR_FRAME_NO_SHADOWS.
+ * Material: without mr_scene_set_materials the uniform Phong material of `diffuse` (what mr_shade_direct shades, and the
+ * batched equivalence above holds bit for bit); once the scene has a material table, Phong::shade uses the material of the
+ * object that was hit (Phong.cpp:116-156) and lets light through refractive occluders scaled by dot(N, l) of the occluder
+ * (Phong.cpp:99-113) -- `diffuse` is ignored, the frame equals mr_trace_level(MR_LEVEL_LAST) over the eye rays, and
+ * MR_TRACE_ANY is refused when a material is refractive (MR_ERR_STATE); default traversal only. */
 typedef struct mr_frame_desc {
     mr_camera camera;
     uint32_t  W, H, y0, y1;

@@ -135,3 +135,79 @@ def test_material_argument_checks(miro):
     s.add_triangle([0, 0, 0, 1, 0, 0, 0, 1, 0], [0, 0, 1] * 3)
     with pytest.raises(miro.MiroError):
         s.set_materials([phong((1, 1, 1))], np.array([3], np.uint32))      # material id out of range
+
+
+@pytest.mark.parametrize("W,H,spp", [(160, 120, 1), (96, 72, 4)])
+def test_direct_frame_lets_light_through_a_glass_occluder(oracle, miro, W, H, spp):
+    """mr_render_direct in a scene with a material table (VERDICT r2 item 7): Phong::shade with the material of the object
+    that was hit and light through the refractive ball scaled by dot(N, l) of the ball (Phong.cpp:99-113) -- the oracle's
+    traceScene at depth 0 is exactly Phong::shade of the primary hit (Scene.cpp:278-284; its children return at depth -1)."""
+    import torch
+    from miro_amd import binding
+    a, b, mats11, prim_mat = build_both(oracle, miro)
+    d = scenes.SCENES["teapot"]
+    fu = mframe.FusedFrame(b, d, W, H, spp=spp, keep_hits=True, tiled=False)
+    fu.step()
+    torch.cuda.synchronize()
+    got = fu.d_rgb.cpu().numpy().astype(np.float64)
+    rays = oracle.eye_rays(camera_of(oracle, "teapot"), W, H, spp=spp, jitter=spp > 1, seed=168)
+    want_rays, calls = a.trace_scene(mats11, prim_mat, rays, d["light"], d["wattage"], depth=0)
+    want = want_rays.reshape(H * W, spp, 3).astype(np.float64).mean(axis=1)
+    n_p, n_s = fu.ray_counts()
+    assert calls == n_p + n_s                                     # one Scene::trace per eye ray and per shadow ray
+    scale = np.abs(want).max()
+    err = np.abs(got - want)
+    assert scale > 0 and err.max() <= 2e-4 * scale and np.median(err) <= 1e-6 * scale
+    # the case is live: some samples' nearest occluder is the glass ball and they are lit (an opaque ball would zero them)
+    sh = fu.d_shadow_hits.cpu().numpy().view(miro.HIT_DTYPE).reshape(-1)
+    n_teapot = int((prim_mat == 0).sum())
+    through_glass = (sh["prim"] != miro.MISS) & (sh["prim"] >= n_teapot) & (sh["prim"] < n_teapot + int((prim_mat == 1).sum()))
+    lit = want_rays.reshape(-1, 3).max(axis=1) > 0
+    assert (through_glass & lit).sum() > 20, "no sample sees the light through the glass ball"
+    # the same frame, one level of the recursion in one launch over resident eye rays (mr_trace_level, MR_LEVEL_LAST)
+    fr = mframe.FrameRenderer(b, d, W, H, spp=spp)
+    fr.generate()
+    fr.render_specular(depth=0, fused=True)
+    torch.cuda.synchronize()
+    assert torch.allclose(fr.d_rgb, fu.d_rgb, rtol=1e-6, atol=1e-7 * float(scale))
+    if spp == 1:
+        assert torch.equal(fr.d_rgb, fu.d_rgb)                    # one sample per pixel: no summation order to differ by
+    # calls that would get it wrong refuse: the flag-per-ray occlusion of mr_shade_direct, any-hit shadow rays
+    with pytest.raises(miro.MiroError) as e:
+        fr.step()
+    assert e.value.status == binding.MR_ERR_STATE
+    with pytest.raises(miro.MiroError) as e:
+        mframe.FusedFrame(b, d, W, H, spp=spp, any_shadow=True).step()
+    assert e.value.status == binding.MR_ERR_STATE
+
+
+def test_frame_without_shadow_rays_is_the_disable_shadows_build(oracle, miro):
+    """MR_FRAME_NO_SHADOWS = the reference's -DDISABLE_SHADOWS (Phong.cpp:91): BASELINE config 2, teapot 512x512 primary rays
+    only -- 262 144 rays, no shadow ray traced (the write-up's count, Readme.tex:99), every hit lit as if nothing occluded it."""
+    import torch
+    from helpers import oracle_scene, product_scene
+    name, W, H = "teapot", 512, 512
+    d = scenes.SCENES[name]
+    a, b = oracle_scene(oracle, name), product_scene(miro, name)
+    fu = mframe.FusedFrame(b, d, W, H, spp=1, keep_hits=True, tiled=False, no_shadows=True)
+    fu.step()
+    torch.cuda.synchronize()
+    assert fu.ray_counts() == (262144, 0)
+    rays = oracle.eye_rays(camera_of(oracle, name), W, H)
+    hits = a.trace(rays)
+    assert fu.d_hits.cpu().numpy().tobytes() == hits.tobytes()
+    assert int((hits["prim"] != oracle.MISS).sum()) == 222390                       # SURVEY section 4
+    sh = fu.d_shadow_hits.cpu().numpy().view(miro.HIT_DTYPE).reshape(-1)
+    assert (sh["prim"] == miro.MISS).all() and (sh["t"] == 0).all()
+    want = a.shade_direct(rays, hits, np.zeros(len(rays), np.uint8), d["light"], d["wattage"], spp=1)
+    got = fu.d_rgb.cpu().numpy()
+    assert want.max() > 0 and np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+    # with materials: the unoccluded Phong::shade of the hit's own material = the shadowed frame wherever nothing occludes
+    a2, b2, mats11, prim_mat = build_both(oracle, miro)
+    f_on = mframe.FusedFrame(b2, d, 160, 120, spp=1, keep_hits=True, tiled=False)
+    f_off = mframe.FusedFrame(b2, d, 160, 120, spp=1, tiled=False, no_shadows=True)
+    f_on.step(); f_off.step()
+    torch.cuda.synchronize()
+    free = (f_on.d_shadow_hits[:, 1].view(torch.int32) == -1)
+    assert free.any() and torch.equal(f_on.d_rgb[free], f_off.d_rgb[free])
+    assert (f_off.d_rgb[~free].sum(dim=1) >= f_on.d_rgb[~free].sum(dim=1)).all()
