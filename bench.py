@@ -147,10 +147,11 @@ def _counter_means(out_dir, kernel_substr):
     return {k: sum(v) / len(v) for k, v in acc.items()}, (max((len(v) for v in acc.values()), default=0))
 
 
-def live_pmc(argv_leg, kernel_substr, timeout_s=120):
+def live_pmc(argv_leg, kernel_substr, timeout_s=120, passes=None):
     """Three rocprofv3 --pmc passes (SQ counters; FETCH_SIZE; WRITE_SIZE -- the TCC pair does not fit one pass) over
     `python3 bench.py --pmc-leg ...`, i.e. over the same frame this run times.  Returns the counter means per launch of
     the frame kernel, or None when the profiler is missing / fails / times out."""
+    passes = passes or (("sq", SQ_COUNTERS), ("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"))
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
@@ -158,7 +159,7 @@ def live_pmc(argv_leg, kernel_substr, timeout_s=120):
     tmp = tempfile.mkdtemp(prefix="miro_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     try:
-        for tag, counters in (("sq", SQ_COUNTERS), ("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        for tag, counters in passes:
             d = os.path.join(tmp, tag)
             cmd = [exe, "--pmc"] + counters.split() + ["--output-format", "csv", "-d", d, "--", sys.executable,
                                                        os.path.abspath(__file__)] + argv_leg
@@ -185,6 +186,236 @@ def committed_pmc(workload):
     except Exception:
         return None
     return j if j.get("per_sample") else None      # per-sample figures: scaled to the launch at hand by the caller
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE config 5
+PHOTON_PASSES = (("sq", SQ_COUNTERS),
+                 ("lds", "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD"),
+                 ("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"))
+
+
+def photon_cpu_baseline(po, maps_np, P, N, k, max_dist, n_sample):
+    """The oracle's Photon_map::irradiance_estimate (a port of PhotonMap.cpp:81-243) on a bounded sample of the same
+    queries, both maps, on the host cores this process may use (one chunk of queries per thread; ctypes releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    affinity = len(os.sched_getaffinity(0))
+    quota = cgroup_cpu_quota()
+    threads = int(os.environ.get("MIRO_CPU_THREADS", "0")) or (affinity if quota is None else max(1, min(affinity, int(quota + 0.999))))
+    threads = min(threads, 64)
+    maps = []
+    for pw, pos, d in maps_np:
+        m = po.PhotonMap(len(pos) + 10)
+        m.store(pw, pos, d)
+        m.scale_photon_power(1.0 / len(pos))
+        m.balance()
+        maps.append(m)
+    idx = np.linspace(0, len(P) - 1, n_sample).astype(np.int64)          # spread over the frame
+    Ps, Ns = P[idx], N[idx]
+    chunks = np.array_split(np.arange(n_sample), threads * 4)
+
+    def work(c):
+        for m in maps:
+            m.irradiance_estimate(Ps[c], Ns[c], max_dist=max_dist, nphotons=k)
+        return len(c)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        done = sum(ex.map(work, chunks))
+    secs = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    one = min(n_sample, 2000)
+    for m in maps:
+        m.irradiance_estimate(Ps[:one], Ns[:one], max_dist=max_dist, nphotons=k)
+    s1 = time.perf_counter() - t1
+    return dict(value=round(done * len(maps) / secs / 1e6, 4), unit="Mqueries/s", cores=threads, kind="port",
+                threads_used=threads, affinity_cores=affinity, cgroup_quota_cores=quota, host_cpus=os.cpu_count(),
+                single_thread_mqueries_s=round(one * len(maps) / s1 / 1e6, 5),
+                sample="%d of the frame's %d query points x %d maps, k = %d: the oracle's restated locate_photons / "
+                       "irradiance_estimate (oracle/miro_oracle_photon.c), %d threads, %.2f s wall" % (n_sample, len(P), len(maps), k, threads, secs))
+
+
+def photon_main(a, world, rank, local_dev, dev, red_dev, backend):
+    """BASELINE config 5: "sponza.obj + PhotonMap final-gather rays (PhotonMap.cpp kNN lookup as second HIP kernel)".
+    Queries = hit point + normalised normal of every primary hit of config 4's frame at 1 spp (Scene.cpp:285-292), built
+    on the device by the library; two maps of --photons photons each (Scene.h:67-68), k = PHOTON_SAMPLES = 500,
+    max_dist = 1e10 (Miro.h:16-17).  A step = Photon_map::irradiance_estimate for every query on both maps
+    (mr_irradiance_estimate x 2; queries resident in HBM).  value = estimates per second, whole job."""
+    desc = scenes.SCENES["sponza"]
+    label = scenes.sponza_label()
+    if rank == 0:
+        scenes.sponza_path()
+    if world > 1:
+        dist.barrier()
+    scene = miro_amd.Scene(local_dev)
+    scenes.populate(scene, desc)
+    info = scene.build(4)
+    W, H, k, max_dist = a.width, a.height, a.k, 1e10
+    band = next((b for b in range(8, 0, -1) if H % b == 0 and (H // b) % world == 0), 8)
+    bands = mframe.band_rows(H, band, rank, world)
+    fr = mframe.FrameRenderer(scene, desc, W, H, spp=1, bands=bands, jitter=False)
+    fr.generate()
+    fr.trace_primary()
+    n = fr.n
+    v, _, vi, _ = scene.arrays()
+    maps_np = [scenes.synthetic_photons(v, vi, a.photons, seed) for seed in (168, 169)]
+    t_bal = time.perf_counter()
+    maps = []
+    for pw, pos, d in maps_np:
+        m = miro_amd.PhotonMap(a.photons + 10, device=local_dev)
+        m.store(pw, pos, d)
+        m.scale_photon_power(1.0 / a.photons)
+        m.balance()
+        maps.append(m)
+    t_bal = time.perf_counter() - t_bal
+    # the library's own query construction (gather_queries_kernel): one whole mr_final_gather, whose scratch then holds
+    # positions [0,3n) and normals [3n,6n); also the warm-up of the kernels
+    scratch = torch.empty(12 * max(n, 1), dtype=torch.float32, device=dev)
+    rgb = torch.zeros((max(fr.n_pixels, 1), 3), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream()
+    if n:
+        scene.final_gather(maps[0], maps[1], fr.d_rays, fr.d_hits, n, scratch, rgb, max_dist=max_dist, nphotons=k, spp=1, stream=stream)
+    P, N = scratch[:3 * n].view(n, 3), scratch[3 * n:6 * n].view(n, 3)
+    nq = int((N[:, 0] == N[:, 0]).sum().item()) if n else 0           # NaN normal = no query (miss / non-diffuse hit)
+    out = torch.empty((max(n, 1), 3), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+
+    def one_step(events=None):
+        for m in maps:
+            e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if events is not None else None
+            if e: e[0].record(stream)
+            if n:
+                m.irradiance_estimate(P, N, n, out, max_dist=max_dist, nphotons=k, stream=stream)
+            if e:
+                e[1].record(stream)
+                events.append(e)
+
+    if a.pmc_leg:
+        for _ in range(2):
+            one_step()
+        torch.cuda.synchronize()
+        print("PMC_LEG queries_per_launch=%d" % nq)
+        return
+    for _ in range(a.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    events = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_step(events)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tot = torch.tensor([float(nq * len(maps)), elapsed], dtype=torch.float64, device=red_dev)
+    ranks_seen = 1
+    if world > 1:
+        q_all, tmax, ones = tot[0:1].clone(), tot[1:2].clone(), torch.ones(1, dtype=torch.float64, device=red_dev)
+        dist.all_reduce(q_all, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        est_per_step, elapsed, ranks_seen = float(q_all.item()), float(tmax.item()), int(round(float(ones.item())))
+    else:
+        est_per_step = float(nq * len(maps))
+    if rank == 0:
+        ms = [e0.elapsed_time(e1) for e0, e1 in events]
+        avg_ms = sum(ms) / max(len(ms), 1)
+        launch_s = avg_ms * 1e-3
+        # work counters of one launch per map (the counting build of the kernel), outside the timed region
+        work = {}
+        for name, m in zip(("global", "caustic"), maps):
+            m.count_stats(True)
+            m.irradiance_estimate(P, N, n, out, max_dist=max_dist, nphotons=k, stream=stream)
+            work[name] = m.stats()
+            m.count_stats(False)
+        rec_search = sum(w["records_searched"] for w in work.values()) / len(maps)
+        rec_pre = sum(w["records_prepass"] for w in work.values()) / len(maps)
+        alg_bytes = 32.0 * (rec_search + rec_pre) + 24.0 * nq + 12.0 * nq        # records + query in + irradiance out
+        workload = "%s %dx%d 1spp hits: %d queries x 2 photon maps of %d, k=%d" % (label, W, H, int(est_per_step / len(maps)), a.photons, k)
+        pmc, pmc_source, pmc_note = None, None, None
+        if world == 1 and not a.no_pmc:
+            leg = ["--config", "photon", "--pmc-leg", "--no-cpu-baseline", "--no-pmc", "--width", str(W), "--height", str(H),
+                   "--photons", str(a.photons), "--k", str(k), "--steps", "1", "--warmup", "0"]
+            pmc, pmc_note = live_pmc(leg, "irradiance_kernel", timeout_s=300, passes=PHOTON_PASSES)
+            if pmc:
+                pmc_source = "live: rocprofv3 --pmc passes over this workload, started by this run"
+                try:
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    json.dump({"workload": workload, "kernel": "irradiance_kernel", "queries_per_launch": nq,
+                               "counters_per_launch": pmc, "work_counters": work},
+                              open(os.path.join(ROOT, "gpurun_out", "%s_photon_pmc.json" % ROUND_TAG), "w"), indent=1)
+                except Exception:
+                    pass
+        if pmc is None:
+            try:
+                rec = json.load(open(os.path.join(ROOT, "profiles", "%s_photon_pmc.json" % ROUND_TAG)))
+                sc_ = nq / float(rec["queries_per_launch"])
+                pmc = {kk: vv * sc_ for kk, vv in rec["counters_per_launch"].items() if not kk.startswith("dispatches_")}
+                pmc_source = "committed: profiles/%s_photon_pmc.json (%s), scaled per query to this launch" % (ROUND_TAG, rec.get("workload"))
+            except Exception:
+                pmc = None
+        roof = {"kernel": "irradiance_kernel (one launch per photon map and step)", "avg_launch_ms": round(avg_ms, 4),
+                "launches_per_step": len(maps), "pmc_source": pmc_source,
+                "work_per_launch": {"queries": nq, "blocks_of_63_nodes": round(sum(w["blocks"] for w in work.values()) / len(maps)),
+                                    "records_searched": round(rec_search), "records_prepass": round(rec_pre),
+                                    "tightenings": round(sum(w["tightenings"] for w in work.values()) / len(maps)),
+                                    "repeated_searches": round(sum(w["repeated_searches"] for w in work.values()) / len(maps)),
+                                    "records_per_query": round((rec_search + rec_pre) / max(nq, 1), 1)},
+                "algorithmic_bytes_per_launch": round(alg_bytes),
+                "algorithmic_definition": "32 B per photon record examined (device counters: cooperative search + reference-order "
+                                          "pre-pass) + 24 B query in + 12 B irradiance out",
+                "hbm": {"peak_GBps": HBM_PEAK_GBPS, "nominal_algorithmic_GBps": round(alg_bytes / launch_s / 1e9, 1) if launch_s > 0 else None,
+                        "nominal_label": "algorithmic bytes over kernel time; the 9.6 MB of photon records are L2 / MALL resident, so this is not the bound"}}
+        if pmc_note:
+            roof["pmc_note"] = pmc_note
+        if pmc and pmc.get("SQ_INSTS_VALU") and launch_s > 0:
+            valu = pmc["SQ_INSTS_VALU"] / launch_s / 1e9
+            roof.update({"bound": "valu_issue", "unit": "Ginstr/s", "peak": round(VALU_PEAK_GINSTR, 1), "achieved": round(valu, 1),
+                         "frac": round(valu / VALU_PEAK_GINSTR, 4),
+                         "valu_insts_per_query": round(pmc["SQ_INSTS_VALU"] / max(nq, 1), 1),
+                         "salu_insts_per_query": round(pmc.get("SQ_INSTS_SALU", 0) / max(nq, 1), 1)})
+            if pmc.get("SQ_THREAD_CYCLES_VALU"):
+                roof["lane_utilisation"] = round(pmc["SQ_THREAD_CYCLES_VALU"] / pmc["SQ_INSTS_VALU"] / 64.0, 4)
+            if pmc.get("SQ_WAVE_CYCLES"):
+                wc = pmc["SQ_WAVE_CYCLES"]
+                roof["wave_cycle_split"] = {"waiting": round(pmc.get("SQ_WAIT_ANY", 0) / wc, 3), "issue_stalled": round(pmc.get("SQ_WAIT_INST_ANY", 0) / wc, 3)}
+            if pmc.get("SQ_INSTS_LDS") is not None:
+                roof["lds"] = {"insts_per_query": round(pmc["SQ_INSTS_LDS"] / max(nq, 1), 1),
+                               "bank_conflict_cycle_share": round(pmc.get("SQ_LDS_BANK_CONFLICT", 0) / max(pmc.get("SQ_LDS_IDX_ACTIVE", 1), 1), 4),
+                               "issue_stall_share_of_wave_cycles": round(pmc.get("SQ_WAIT_INST_LDS", 0) / max(pmc.get("SQ_WAVE_CYCLES", wc), 1), 4)}
+        else:
+            roof.update({"bound": "valu_issue", "unit": "Ginstr/s", "peak": round(VALU_PEAK_GINSTR, 1), "achieved": None, "frac": None})
+        traffic = None
+        if pmc and pmc.get("FETCH_SIZE") is not None and pmc.get("WRITE_SIZE") is not None:
+            traffic = (pmc["FETCH_SIZE"] * 2.0 + pmc["WRITE_SIZE"]) * 1024.0
+        roof["traffic"] = round(traffic) if traffic is not None else None
+        if traffic is not None and launch_s > 0:
+            roof["hbm"]["measured_GBps"] = round(traffic / launch_s / 1e9, 1)
+            roof["hbm"]["hbm_measured_frac"] = round(traffic / launch_s / 1e9 / HBM_PEAK_GBPS, 4)
+        outj = {"metric": "Mqueries/s (photon-map irradiance estimates, k=%d)" % k, "value": round(est_per_step * a.steps / elapsed / 1e6, 3),
+                "unit": "Mqueries/s", "n_gpus": world, "rccl_ranks": ranks_seen if backend == "nccl" or world == 1 else 0,
+                "dist_backend": backend if world > 1 else None, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic" if label != "sponza" else "real",
+                "config": {"workload": workload, "estimates_per_step": int(est_per_step), "photons_per_map": a.photons, "k": k,
+                           "max_dist": max_dist, "scene_triangles": int(info.n_triangles),
+                           "step": "mr_irradiance_estimate on the global and on the caustic map for every query (queries resident in HBM)",
+                           "photon_maps": "synthetic: photons uniform on the scene's surfaces, cosine-distributed directions, seeds 168 / 169 (SURVEY 8d)",
+                           "balance_and_upload_s": round(t_bal, 3),
+                           "parallelism": "queries of the frame's interleaved row bands of %d over %d GPU(s), maps replicated, no collective" % (band, world)},
+                "roofline": roof}
+        if world == 1 and not a.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import pyoracle as po
+            Ph, Nh = P.cpu().numpy(), N.cpu().numpy()
+            keep = Nh[:, 0] == Nh[:, 0]
+            outj["cpu_baseline"] = photon_cpu_baseline(po, maps_np, Ph[keep], Nh[keep], k, max_dist, a.cpu_queries)
+        print(json.dumps(outj))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def spawn_ranks(n_ranks):
@@ -233,7 +464,7 @@ def spawn_ranks(n_ranks):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)      # 50 x 19 ms: a timed region of about a second
+    ap.add_argument("--steps", type=int, default=None)    # default: 50 frames (50 x 17 ms: about a second) / 5 photon steps
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default="sponza")
     ap.add_argument("--width", type=int, default=1920)
@@ -257,10 +488,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 passes (use the committed profiles/rNN_bench_pmc.json)")
     ap.add_argument("--pmc-leg", action="store_true", help=argparse.SUPPRESS)   # internal: the profiled child
+    ap.add_argument("--config", choices=["frame", "photon"], default="frame",
+                    help="frame: BASELINE config 4 (the default); photon: BASELINE config 5, Photon_map::irradiance_estimate on the "
+                         "frame's primary hits")
+    ap.add_argument("--photons", type=int, default=200000, help="--config photon: photons per map (Scene.h:67-68)")
+    ap.add_argument("--k", type=int, default=500, help="--config photon: PHOTON_SAMPLES (Miro.h:16)")
+    ap.add_argument("--cpu-queries", type=int, default=20000, help="--config photon: queries of the CPU baseline sample")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, rendezvous, count them with an all-reduce, print {n_gpus, rccl_ranks} and stop: "
                          "checks the launch path on a box without GPUs (with MIRO_DIST_BACKEND=gloo); renders nothing")
     a = ap.parse_args()
+    if a.steps is None:
+        a.steps = 5 if a.config == "photon" else 50
 
     if a.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -308,6 +547,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if a.config == "photon":
+        return photon_main(a, world, rank, local_dev, dev, red_dev, backend)
     desc = scenes.SCENES[a.scene]
     label = scenes.sponza_label() if a.scene == "sponza" else a.scene
     if a.scene == "sponza" and rank == 0:

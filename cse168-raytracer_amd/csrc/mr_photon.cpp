@@ -53,6 +53,7 @@ struct mr_photon_map {
     std::vector<int16_t> plane;
     bool balanced = false, on_device = false;
     PhotonMapDev dev;
+    unsigned long long *d_stats = nullptr;   // work counters of the estimates (mr_photon_map_count_stats), else NULL
     uint32_t count() const { return (uint32_t)theta.size(); }
 };
 
@@ -119,8 +120,9 @@ struct Balancer {
 };
 
 void release(mr_photon_map *m) {
-    (void)hipFree(m->dev.posplane); (void)hipFree(m->dev.dir); (void)hipFree(m->dev.power);
+    (void)hipFree(m->dev.posplane); (void)hipFree(m->dev.dir); (void)hipFree(m->dev.power); (void)hipFree(m->d_stats);
     m->dev = PhotonMapDev();
+    m->d_stats = nullptr;
     m->on_device = false;
 }
 
@@ -258,8 +260,35 @@ mr_status mr_irradiance_estimate(mr_photon_map *m, const float *d_pos, const flo
     if (!d_pos || !d_normal || !d_irrad) return fail(MR_ERR_INVALID, "NULL argument");
     if (nphotons == 0 || nphotons > kKnnMaxK) return fail(MR_ERR_INVALID, "nphotons must be in [1, %d]", kKnnMaxK);
     MR_HIP_CHECK(hipSetDevice(m->device));
-    return launch_irradiance(m->dev, d_pos, d_normal, n_queries, max_dist, nphotons, d_irrad, d_found, d_r2,
+    return launch_irradiance(m->dev, d_pos, d_normal, n_queries, max_dist, nphotons, d_irrad, d_found, d_r2, m->d_stats,
                              static_cast<hipStream_t>(stream));
+}
+
+mr_status mr_photon_map_count_stats(mr_photon_map *m, int32_t enable) {
+    if (!m) return fail(MR_ERR_INVALID, "photon map is NULL");
+    if (!m->on_device) return fail(MR_ERR_STATE, "photon map is not resident on a device");
+    MR_HIP_CHECK(hipSetDevice(m->device));
+    if (enable && !m->d_stats) {
+        MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->d_stats), kPhotonStats * sizeof(unsigned long long)));
+        MR_HIP_CHECK(hipMemset(m->d_stats, 0, kPhotonStats * sizeof(unsigned long long)));
+    } else if (!enable && m->d_stats) {
+        MR_HIP_CHECK(hipDeviceSynchronize());
+        (void)hipFree(m->d_stats);
+        m->d_stats = nullptr;
+    }
+    return MR_OK;
+}
+
+mr_status mr_photon_map_get_stats(mr_photon_map *m, uint64_t out[6], int32_t reset) {
+    if (!m || !out) return fail(MR_ERR_INVALID, "NULL argument");
+    if (!m->d_stats) return fail(MR_ERR_STATE, "mr_photon_map_count_stats has not been enabled on this map");
+    MR_HIP_CHECK(hipSetDevice(m->device));
+    MR_HIP_CHECK(hipDeviceSynchronize());
+    unsigned long long h[kPhotonStats];
+    MR_HIP_CHECK(hipMemcpy(h, m->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < kPhotonStats; i++) out[i] = h[i];
+    if (reset) MR_HIP_CHECK(hipMemset(m->d_stats, 0, sizeof(h)));
+    return MR_OK;
 }
 
 mr_status mr_final_gather(mr_scene *s, mr_photon_map *global_map, mr_photon_map *caustic_map, const mr_ray *d_rays,
@@ -284,7 +313,7 @@ mr_status mr_final_gather(mr_scene *s, mr_photon_map *global_map, mr_photon_map 
     if (st != MR_OK) return st;
     for (int i = 0; i < 2; i++) {
         if (!maps[i]) { d_irr[i] = nullptr; continue; }
-        st = launch_irradiance(maps[i]->dev, d_pos, d_nrm, n, max_dist, nphotons, d_irr[i], nullptr, nullptr, stream);
+        st = launch_irradiance(maps[i]->dev, d_pos, d_nrm, n, max_dist, nphotons, d_irr[i], nullptr, nullptr, maps[i]->d_stats, stream);
         if (st != MR_OK) return st;
     }
     return launch_gather_accumulate(d_irr[0], d_irr[1], n, spp, d_rgb, stream);

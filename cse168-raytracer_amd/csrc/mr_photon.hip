@@ -133,7 +133,7 @@ __device__ __forceinline__ float compress(WaveLds &w, int &count, int k, int lan
 // right after that replacement: the largest distance among the first k+1 candidates without m* -- every later
 // replacement only shrinks it, so the cooperative search may start from it instead of from max_dist^2.
 __device__ __forceinline__ int first_overflow(const PhotonMapDev &pm, float qx, float qy, float qz, float nx, float ny, float nz,
-                                              float md2, int k, float &radius_after) {
+                                              float md2, int k, float &radius_after, unsigned &visits) {
     radius_after = md2;
     if (pm.n < 1) return 0;
     int i = 1, cnt = 0, best_i = 0;
@@ -153,6 +153,7 @@ __device__ __forceinline__ int first_overflow(const PhotonMapDev &pm, float qx, 
         }
         // the photon at node i (:177-186)
         {
+            visits++;
             const float4 A = pm.posplane[i], D = pm.dir[i];
             float dd = A.x - qx;
             float d2 = dd * dd;
@@ -184,9 +185,13 @@ __device__ __forceinline__ int first_overflow(const PhotonMapDev &pm, float qx, 
     }
 }
 
+// STATS: work counters of the launch, added to stats[0..5] (mr_photon_map_get_stats): queries answered, blocks expanded,
+// photon records examined by the cooperative search (32 bytes each: position + direction), radius tightenings,
+// photon records examined by the reference-order pre-pass, searches repeated with the safe radius.
+template <bool STATS>
 __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, const float *qpos, const float *qnrm,
                                                             unsigned long long nq, float max_dist, int k, float *irrad,
-                                                            int *found_out, float *r2_out) {
+                                                            int *found_out, float *r2_out, unsigned long long *stats) {
     __shared__ WaveLds s_w[kWaves];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     WaveLds &w = s_w[wv];
@@ -198,6 +203,7 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
     const bool node_lane = lane < 63;
 
     const float md2 = max_dist * max_dist;
+    unsigned long long st_queries = 0, st_blocks = 0, st_records = 0, st_tighten = 0, st_prepass = 0, st_retries = 0;
     // a wave takes 64 consecutive queries at a time: first every lane finds its own query's m* (first_overflow), then
     // the wave searches the 64 queries one after the other
     for (unsigned long long base = wave_id * 64ull; base < nq; base += n_waves * 64ull) {
@@ -205,14 +211,27 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
       float my_radius = md2;
       {
           const unsigned long long qa = base + (unsigned)lane;
+          unsigned visits = 0;
           if (qa < nq) {
               const float ax = qnrm[3 * qa];
               if (ax == ax)
                   my_mstar = first_overflow(pm, qpos[3 * qa], qpos[3 * qa + 1], qpos[3 * qa + 2], ax, qnrm[3 * qa + 1], qnrm[3 * qa + 2], md2, k,
-                                            my_radius);
+                                            my_radius, visits);
+          }
+          if (STATS) {
+              for (int off = 32; off > 0; off >>= 1) visits += __shfl_xor(visits, off, 64);
+              st_prepass += visits;
           }
       }
       const int n_here = nq - base < 64ull ? (int)(nq - base) : 64;
+      // The previous query of this wave (the neighbouring pixel) and its final radius: a GUESS for this one's.  If both
+      // queries saw the same candidates the k-th nearest of this one would lie within sqrt(prev) + |q - q_prev| (triangle
+      // inequality); they need not (the facing test depends on the normal, m* differs), so the guess is verified: a search
+      // inside the guessed radius that finds at least k candidates has found the k nearest (anything nearer than the k-th
+      // is inside the radius too) and the result is the full search's; one that finds fewer is repeated with the safe
+      // radius of the pre-pass.  A tighter start means fewer blocks that touch the sphere.
+      bool prev_ok = false;
+      float prev_r2 = 0.0f, pqx = 0.0f, pqy = 0.0f, pqz = 0.0f;
       for (int t = 0; t < n_here; t++) {
         const unsigned long long q = base + (unsigned)t;
         const int mstar = __shfl(my_mstar, t, 64);            // 0: this query never overflows
@@ -230,9 +249,21 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
         // np.dist2[0]: max_dist^2 (PhotonMap.cpp:99) until the first overflow; for a query that overflows, the reference's
         // radius right after the overflow bounds everything that can still enter the result -- one ulp is added because the
         // photon AT that distance is in the set while candidates must be strictly nearer than the radius
-        float r2 = mstar != 0 ? __uint_as_float(__float_as_uint(radius0) + 1u) : md2;
-        int count = 0;
-        bool evicted = false;
+        const float safe_r2 = mstar != 0 ? __uint_as_float(__float_as_uint(radius0) + 1u) : md2;
+        float r2 = safe_r2;
+        bool guessed = false;
+        if (prev_ok && mstar != 0) {
+            float dx = qx - pqx, dy = qy - pqy, dz = qz - pqz;
+            const float g = sqrtf(prev_r2) + sqrtf((dx * dx + dy * dy) + dz * dz);
+            const float g2 = (g * g) * 1.0001f;               // strictly beyond the would-be k-th photon; only a guess anyway
+            if (g2 < safe_r2) { r2 = g2; guessed = true; }
+        }
+        int count;
+        bool evicted;
+        if (STATS) st_queries++;
+      search_again:
+        count = 0;
+        evicted = false;
         int sp = 0;
         if (pm.n >= 1) { if (lane == 0) { w.stack[0] = 1; w.lb[0] = 0.0f; } sp = 1; }
 
@@ -249,6 +280,7 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
             const int j = valid ? jj : 0;
             float4 A = make_float4(0.f, 0.f, 0.f, 0.f), D = make_float4(0.f, 0.f, 0.f, 0.f);
             if (valid) { A = pm.posplane[j]; D = pm.dir[j]; }
+            if (STATS) { st_blocks++; st_records += (unsigned)__popcll(__ballot(valid)); }
             const int plane = __float_as_int(A.w);
             const float pc = plane == 0 ? A.x : (plane == 1 ? A.y : A.z);
             const float qc = plane == 0 ? qx : (plane == 1 ? qy : qz);
@@ -297,41 +329,55 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
             count += __popcll(mc);
             // children of the level-5 nodes become block roots, pushed so that they pop in the reference's order:
             // key = far-step bits of the whole path (6 bits, unique per child); slot[key] is filled by its owner,
-            // then lane `key` moves it to the stack behind all larger keys
-            lds_handoff();                                    // candidate append above / slot reuse below
-            w.slot[lane] = 0;
-            lds_handoff();
-            const bool can_push = valid && lv == 5 && reach && desc;
-            const int near_child = d1 > 0.0f ? 2 * j + 1 : 2 * j;
-            const int far_child = near_child ^ 1;
-            const float dsq = d1 * d1;
-            if (can_push && near_child <= pm.n) { w.slot[path << 1] = near_child; w.slot_lb[path << 1] = lb; }
-            if (can_push && far_child <= pm.n && dsq < r2) { w.slot[(path << 1) | 1] = far_child; w.slot_lb[(path << 1) | 1] = fmaxf(lb, dsq); }
-            lds_handoff();                                    // slot[] filled by the level-5 lanes, read by lane `key`
-            const int child = w.slot[lane];
-            const float child_lb = w.slot_lb[lane];
-            const unsigned long long mp = __ballot(child != 0);
-            if (child != 0) {
-                const unsigned long long higher = lane == 63 ? 0ull : (mp >> (lane + 1));
-                const int pos = sp + __popcll(higher);
-                w.stack[pos] = child; w.lb[pos] = child_lb;
+            // then lane `key` moves it to the stack behind all larger keys.  A block whose level-5 nodes do not descend
+            // (b * 32 >= half: the bottom layer of blocks, most of those a query touches) has nothing to push.
+            if ((b << 5) < pm.half) {
+                lds_handoff();                                // candidate append above / slot reuse below
+                w.slot[lane] = 0;
+                lds_handoff();
+                const bool can_push = valid && lv == 5 && reach && desc;
+                const int near_child = d1 > 0.0f ? 2 * j + 1 : 2 * j;
+                const int far_child = near_child ^ 1;
+                const float dsq = d1 * d1;
+                if (can_push && near_child <= pm.n) { w.slot[path << 1] = near_child; w.slot_lb[path << 1] = lb; }
+                if (can_push && far_child <= pm.n && dsq < r2) { w.slot[(path << 1) | 1] = far_child; w.slot_lb[(path << 1) | 1] = fmaxf(lb, dsq); }
+                lds_handoff();                                // slot[] filled by the level-5 lanes, read by lane `key`
+                const int child = w.slot[lane];
+                const float child_lb = w.slot_lb[lane];
+                const unsigned long long mp = __ballot(child != 0);
+                if (child != 0) {
+                    const unsigned long long higher = lane == 63 ? 0ull : (mp >> (lane + 1));
+                    const int pos = sp + __popcll(higher);
+                    w.stack[pos] = child; w.lb[pos] = child_lb;
+                }
+                sp += __popcll(mp);
+                lds_handoff();                                // stack[] / lb[] entries are popped by every lane next round
             }
-            sp += __popcll(mp);
-            lds_handoff();                                    // stack[] / lb[] entries are popped by every lane next round
             if (count > kTighten && count > k) {              // keep the k nearest so far; the k-th is the new radius
+                lds_handoff();                                // the candidates appended above are read by other lanes
                 r2 = compress(w, count, k, lane);
                 evicted = true;
+                if (STATS) st_tighten++;
             }
         }
-        if (count > k) { r2 = compress(w, count, k, lane); evicted = true; }
+        if (guessed && count < k) {                           // the guessed radius does not hold the k nearest: the safe one
+            guessed = false;
+            r2 = safe_r2;
+            if (STATS) st_retries++;
+            lds_handoff();
+            goto search_again;
+        }
+        if (count > k) { lds_handoff(); r2 = compress(w, count, k, lane); evicted = true; if (STATS) st_tighten++; }
         else if (mstar != 0) {
             // exactly k candidates besides m*: the reference's heap holds them all and its root is the farthest
+            lds_handoff();
             float mx = 0.0f;
             for (int i = lane; i < count; i += 64) mx = fmaxf(mx, w.d2[i]);
             for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
             r2 = mx; evicted = true;
         }
         const float r2_final = evicted ? r2 : md2;            // dist2[0] only moves once the heap overflows (:240)
+        prev_ok = evicted; prev_r2 = r2_final; pqx = qx; pqy = qy; pqz = qz;
         lds_handoff();
         float sr = 0.f, sg = 0.f, sb = 0.f;
         for (int i = lane; i < count; i += 64) {
@@ -349,19 +395,28 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
         }
       }
     }
+    if (STATS && lane == 0 && stats) {
+        atomicAdd(&stats[0], st_queries); atomicAdd(&stats[1], st_blocks); atomicAdd(&stats[2], st_records);
+        atomicAdd(&stats[3], st_tighten); atomicAdd(&stats[4], st_prepass); atomicAdd(&stats[5], st_retries);
+    }
 }
 
 }  // namespace
 
 mr_status launch_irradiance(const PhotonMapDev &pm, const float *d_pos, const float *d_normal, unsigned long long nq,
-                            float max_dist, uint32_t k, float *d_irrad, int32_t *d_found, float *d_r2, hipStream_t stream) {
+                            float max_dist, uint32_t k, float *d_irrad, int32_t *d_found, float *d_r2, unsigned long long *d_stats,
+                            hipStream_t stream) {
     static_assert(kTighten + 64 <= kCap && kKnnMaxK <= kTighten, "candidate buffer must hold k plus one block");
     if (pm.n >= (1 << 24))
         return fail(MR_ERR_INVALID, "photon maps of 2^24 photons or more need a deeper block stack (kStack)");
     unsigned long long blocks = (nq + kWaves - 1) / kWaves;
     if (blocks > 256ull * 16ull) blocks = 256ull * 16ull;
-    hipLaunchKernelGGL(irradiance_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, pm, d_pos, d_normal, nq, max_dist,
-                       (int)k, d_irrad, d_found, d_r2);
+    if (d_stats)
+        hipLaunchKernelGGL(irradiance_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, pm, d_pos, d_normal, nq, max_dist,
+                           (int)k, d_irrad, d_found, d_r2, d_stats);
+    else
+        hipLaunchKernelGGL(irradiance_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, pm, d_pos, d_normal, nq, max_dist,
+                           (int)k, d_irrad, d_found, d_r2, d_stats);
     MR_HIP_CHECK(hipGetLastError());
     return MR_OK;
 }

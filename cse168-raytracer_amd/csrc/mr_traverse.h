@@ -319,18 +319,21 @@ __device__ __forceinline__ void node_slabs(const float4 q0, const float4 q1, con
                                            float &mn0, float &mx0, float &mn1, float &mx1);
 template <bool EXACT, bool STATS, int SLAB, int OCT = 8>
 __device__ __forceinline__ void node_slabs_guarded(const float4 q0, const float4 q1, const float4 q2, const RayRegs &r, float best_t,
-                                                   float &mn0, float &mx0, float &mn1, float &mx1);
+                                                   float &mn0, float &mx0, float &mn1, float &mx1, float &k0, float &k1);
 
 // the post-test bookkeeping of BVH.cpp:609-651: near child first (ties -> child 0), far child pushed, else pop
-template <bool STATS, bool SAFE>
+// HAVE_K: the caller already holds k0 = minNum(mx0, best_t), k1 = minNum(mx1, best_t) (node_slabs_guarded computes them for
+// its tie test: recomputing them here cost two VALU instructions per visit of the hot loop)
+template <bool STATS, bool SAFE, bool HAVE_K = false>
 __device__ __forceinline__ void node_decide(float mn0, float mx0, float mn1, float mx1, int ref0, int ref1,
-                                            const RayRegs &r, Lane &L, int *s_stack, Stats &st) {
+                                            const RayRegs &r, Lane &L, int *s_stack, Stats &st, float k0 = 0.0f, float k1 = 0.0f) {
     // tMax of this call == best_t: nothing changed since the node was entered
     bool h0, h1;
     if (SAFE) {
         // mn, mx are not NaN here; (mn > mx || mn > best) == (mn > minNum(mx, best)) also when best is NaN
-        h0 = !((mn0 > vmin2(mx0, L.best_t)) || (mx0 < r.tmin));
-        h1 = !((mn1 > vmin2(mx1, L.best_t)) || (mx1 < r.tmin));
+        if (!HAVE_K) { k0 = vmin2(mx0, L.best_t); k1 = vmin2(mx1, L.best_t); }
+        h0 = !((mn0 > k0) || (mx0 < r.tmin));
+        h1 = !((mn1 > k1) || (mx1 < r.tmin));
     } else {
         h0 = !((mn0 > mx0) || (mn0 > L.best_t) || (mx0 < r.tmin));
         h1 = !((mn1 > mx1) || (mn1 > L.best_t) || (mx1 < r.tmin));
@@ -368,8 +371,9 @@ __device__ __forceinline__ void node_step(const TraceParams &p, const RayRegs &r
                 node_decide<STATS, false>(mn0, mx0, mn1, mx1, __float_as_int(v[12]), __float_as_int(v[13]), r, L, s_stack, st);
                 return;
             }
-            node_slabs_guarded<EXACT, STATS, SLAB, OCT>(q0, q1, q2, r, L.best_t, mn0, mx0, mn1, mx1);
-            node_decide<STATS, kSafe>(mn0, mx0, mn1, mx1, __float_as_int(v[12]), __float_as_int(v[13]), r, L, s_stack, st);
+            float k0 = 0.0f, k1 = 0.0f;
+            node_slabs_guarded<EXACT, STATS, SLAB, OCT>(q0, q1, q2, r, L.best_t, mn0, mx0, mn1, mx1, k0, k1);
+            node_decide<STATS, kSafe, SLAB == 5>(mn0, mx0, mn1, mx1, __float_as_int(v[12]), __float_as_int(v[13]), r, L, s_stack, st, k0, k1);
             return;
         }
     }
@@ -382,8 +386,9 @@ __device__ __forceinline__ void node_step(const TraceParams &p, const RayRegs &r
         node_decide<STATS, false>(mn0, mx0, mn1, mx1, q3.x, q3.y, r, L, s_stack, st);
         return;
     }
-    node_slabs_guarded<EXACT, STATS, SLAB, OCT>(q0, q1, q2, r, L.best_t, mn0, mx0, mn1, mx1);
-    node_decide<STATS, kSafe>(mn0, mx0, mn1, mx1, q3.x, q3.y, r, L, s_stack, st);
+    float k0 = 0.0f, k1 = 0.0f;
+    node_slabs_guarded<EXACT, STATS, SLAB, OCT>(q0, q1, q2, r, L.best_t, mn0, mx0, mn1, mx1, k0, k1);
+    node_decide<STATS, kSafe, SLAB == 5>(mn0, mx0, mn1, mx1, q3.x, q3.y, r, L, s_stack, st, k0, k1);
 }
 
 template <bool EXACT, bool STATS, int SLAB, int OCT>
@@ -429,20 +434,24 @@ __device__ __forceinline__ void node_slabs(const float4 q0, const float4 q1, con
 // Same hits, same visiting order, same bits as SLAB 4 (tests: test_gpu_parity, the fuzz campaigns run both).
 template <bool EXACT, bool STATS, int SLAB, int OCT>
 __device__ __forceinline__ void node_slabs_guarded(const float4 q0, const float4 q1, const float4 q2, const RayRegs &r, float best_t,
-                                                   float &mn0, float &mx0, float &mn1, float &mx1) {
+                                                   float &mn0, float &mx0, float &mn1, float &mx1, float &k0, float &k1) {
     if (SLAB != 5) {
         node_slabs<EXACT, STATS, SLAB, OCT>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
         return;
     }
     node_slabs<EXACT, STATS, 1, OCT>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
-    const float k0 = vmin2(mx0, best_t), k1 = vmin2(mx1, best_t);
-    // smallest of the five pattern distances, in one asm block (separate asm statements are fenced by hazard no-ops)
+    // k = minNum(exit, best_t) of both children and the smallest of the five pattern distances, in ONE asm block (separate
+    // asm statements are fenced by hazard no-ops: three s_nop per visit when the two v_min stood alone)
     unsigned near, t0, t1;
-    asm("v_sad_u32 %0, %3, %4, 0\n\tv_sad_u32 %1, %5, %6, 0\n\tv_sad_u32 %2, %7, %8, 0\n\tv_min3_u32 %0, %0, %1, %2\n\t"
-        "v_sad_u32 %1, %9, %6, 0\n\tv_sad_u32 %2, %3, %7, 0\n\tv_min3_u32 %0, %0, %1, %2"
-        : "=&v"(near), "=&v"(t0), "=&v"(t1)
-        : "v"(mn0), "v"(k0), "v"(mx0), "v"(r.tmin), "v"(mn1), "v"(k1), "v"(mx1));
-    if (__any(near <= 16u)) node_slabs<EXACT, STATS, 4, OCT>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
+    asm("v_min_f32 %3, %8, %10\n\tv_min_f32 %4, %9, %10\n\t"
+        "v_sad_u32 %0, %5, %3, 0\n\tv_sad_u32 %1, %8, %6, 0\n\tv_sad_u32 %2, %7, %4, 0\n\tv_min3_u32 %0, %0, %1, %2\n\t"
+        "v_sad_u32 %1, %9, %6, 0\n\tv_sad_u32 %2, %5, %7, 0\n\tv_min3_u32 %0, %0, %1, %2"
+        : "=&v"(near), "=&v"(t0), "=&v"(t1), "=&v"(k0), "=&v"(k1)
+        : "v"(mn0), "v"(r.tmin), "v"(mn1), "v"(mx0), "v"(mx1), "v"(best_t));
+    if (__any(near <= 16u)) {
+        node_slabs<EXACT, STATS, 4, OCT>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
+        k0 = vmin2(mx0, best_t); k1 = vmin2(mx1, best_t);
+    }
 }
 
 // one 48-byte triangle record through the scalar data cache (all active lanes at the same leaf)

@@ -40,6 +40,7 @@ EXPORTED_SYMBOLS = [
     "mr_scene_set_materials", "mr_shade_accumulate", "mr_gen_secondary_rays",
     "mr_photon_map_create", "mr_photon_map_destroy", "mr_photon_map_store", "mr_photon_map_scale",
     "mr_photon_map_balance", "mr_photon_map_count", "mr_photon_map_export", "mr_irradiance_estimate",
+    "mr_photon_map_count_stats", "mr_photon_map_get_stats",
     "mr_final_gather",
     "mr_last_error", "mr_version",
 ]
@@ -173,6 +174,8 @@ def load_library(path=None):
     L.mr_photon_map_count.argtypes = [vp, u32p]
     L.mr_photon_map_export.argtypes = [vp, f32p, C.POINTER(C.c_int32), C.POINTER(C.c_uint8), f32p]
     L.mr_irradiance_estimate.argtypes = [vp, vp, vp, C.c_uint64, C.c_float, C.c_uint32, vp, vp, vp, vp]
+    L.mr_photon_map_count_stats.argtypes = [vp, C.c_int32]
+    L.mr_photon_map_get_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int32]
     for name in EXPORTED_SYMBOLS:
         if hasattr(L, name) and getattr(L, name).restype is C.c_int:
             getattr(L, name).restype = C.c_int32
@@ -555,3 +558,15 @@ class PhotonMap:
         _check(self.L.mr_irradiance_estimate(self.h, d_pos.data_ptr(), d_normal.data_ptr(), n, max_dist, nphotons,
                                              d_irrad.data_ptr(), d_found.data_ptr() if d_found is not None else None,
                                              d_r2.data_ptr() if d_r2 is not None else None, _stream_ptr(stream)))
+
+    STAT_NAMES = ("queries", "blocks", "records_searched", "tightenings", "records_prepass", "repeated_searches")
+
+    def count_stats(self, enable=True):
+        """mr_photon_map_count_stats: the estimates on this map run the counting build of the kernel while enabled."""
+        _check(self.L.mr_photon_map_count_stats(self.h, 1 if enable else 0))
+
+    def stats(self, reset=True):
+        """mr_photon_map_get_stats as a dict (synchronises the device)."""
+        out = (C.c_uint64 * 6)()
+        _check(self.L.mr_photon_map_get_stats(self.h, out, 1 if reset else 0))
+        return dict(zip(self.STAT_NAMES, (int(v) for v in out)))

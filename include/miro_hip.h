@@ -355,6 +355,14 @@ mr_status mr_photon_map_export(const mr_photon_map *map, float *pos, int32_t *pl
 mr_status mr_irradiance_estimate(mr_photon_map *map, const float *d_pos, const float *d_normal, uint64_t n_queries,
                                  float max_dist, uint32_t nphotons, float *d_irrad, int32_t *d_found, float *d_r2,
                                  void *stream);
+/* Work counters of the estimates on this map, like MR_COUNT_STATS for the traversal (the reference has no counterpart:
+ * Stats.h counts nothing in PhotonMap.cpp).  While enabled, every mr_irradiance_estimate / mr_final_gather on the map runs
+ * the counting build of the kernel and adds to: [0] queries answered, [1] blocks of 63 kd-tree nodes expanded, [2] photon
+ * records (position + direction, 32 bytes) examined by the search, [3] radius tightenings (k-th-nearest selections),
+ * [4] photon records examined by the reference-order pre-pass that finds the first overflow's victim
+ * (PhotonMap.cpp:195-240), [5] searches repeated because a guessed radius did not hold the k nearest. */
+mr_status mr_photon_map_count_stats(mr_photon_map *map, int32_t enable);
+mr_status mr_photon_map_get_stats(mr_photon_map *map, uint64_t counters[6], int32_t reset);
 
 /* The photon-map term of Scene::traceScene (Scene.cpp:285-299) for a traced batch: for every ray whose hit has a
  * diffuse material (Phong::isDiffuse), irradiance_estimate on the global and on the caustic map (either may be NULL)
