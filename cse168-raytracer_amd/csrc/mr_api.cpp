@@ -1,11 +1,13 @@
 // mr_api.cpp -- the extern "C" boundary declared in include/miro_hip.h.
 // Scene assembly and BVH::build run on the host; mr_bvh_build flattens the tree into the device
 // layout of mr_internal.h and uploads it once; mr_trace only moves rays/hits and launches.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "mr_internal.h"
 #include "mr_tile.h"
@@ -65,8 +67,71 @@ inline int32_t leaf_ref(uint32_t first, uint32_t count) {
 
 mr_status upload_materials(mr_scene *s);
 
+// Storage order of the inner nodes (MR_LAYOUT_*): the list of host node indices in the order their records are stored;
+// -1 = an unused padding record.  Node identity, references and visiting order do not depend on it.
+std::vector<int32_t> node_storage_order(const HostTree &t, uint32_t mode) {
+    std::vector<int32_t> order;
+    const auto inner = [&](int32_t n) { return n >= 0 && !t.nodes[(size_t)n].is_leaf; };
+    if (t.nodes.empty() || t.nodes[0].is_leaf) return order;
+    if (mode == MR_LAYOUT_PAIRS) {
+        // pre-order; a node that has an inner child and would start in the second half of a line although it is not the
+        // partner of the record before it moves to the next line: (node, first inner child) always share 128 bytes
+        struct Item { int32_t node; bool partner; };
+        std::vector<Item> stack{{0, false}};
+        while (!stack.empty()) {
+            const Item it = stack.back();
+            stack.pop_back();
+            const HostNode &nd = t.nodes[(size_t)it.node];
+            const int32_t first = inner(nd.a) ? nd.a : (inner(nd.b) ? nd.b : -1);
+            const int32_t other = (first == nd.a && inner(nd.b)) ? nd.b : -1;
+            if (!it.partner && (order.size() & 1) && first >= 0) order.push_back(-1);
+            const bool even = (order.size() & 1) == 0;
+            order.push_back(it.node);
+            if (other >= 0) stack.push_back({other, false});
+            if (first >= 0) stack.push_back({first, even});
+        }
+        return order;
+    }
+    if (mode == MR_LAYOUT_TREELETS) {
+        constexpr int kTop = 12, kTreelet = 3;
+        std::vector<int32_t> frontier{0}, roots;
+        for (int level = 0; level < kTop && !frontier.empty(); level++) {        // breadth-first top
+            std::vector<int32_t> next;
+            for (int32_t n : frontier) {
+                order.push_back(n);
+                for (int32_t c : {t.nodes[(size_t)n].a, t.nodes[(size_t)n].b})
+                    if (inner(c)) next.push_back(c);
+            }
+            frontier.swap(next);
+        }
+        roots = frontier;
+        // below: a treelet = the inner nodes of up to kTreelet levels under its root, breadth-first and contiguous; the
+        // treelets under it follow depth-first
+        std::vector<int32_t> stack(roots.rbegin(), roots.rend());
+        while (!stack.empty()) {
+            const int32_t root = stack.back();
+            stack.pop_back();
+            std::vector<int32_t> level{root}, below;
+            for (int l = 0; l < kTreelet && !level.empty(); l++) {
+                std::vector<int32_t> next;
+                for (int32_t n : level) {
+                    order.push_back(n);
+                    for (int32_t c : {t.nodes[(size_t)n].a, t.nodes[(size_t)n].b})
+                        if (inner(c)) next.push_back(c);
+                }
+                level.swap(next);
+            }
+            for (auto it = level.rbegin(); it != level.rend(); ++it) stack.push_back(*it);
+        }
+        return order;
+    }
+    for (size_t i = 0; i < t.nodes.size(); i++)
+        if (!t.nodes[i].is_leaf) order.push_back((int32_t)i);
+    return order;
+}
+
 // host tree -> device records
-mr_status flatten_and_upload(mr_scene *s) {
+mr_status flatten_and_upload(mr_scene *s, uint32_t layout) {
     const HostTree &t = s->tree;
     const HostMesh &m = s->mesh;
     DeviceScene &d = s->dev;
@@ -75,17 +140,44 @@ mr_status flatten_and_upload(mr_scene *s) {
         return fail(MR_ERR_INVALID, "scene has %u triangles; the leaf reference encoding holds < %u", nt,
                     1u << (31 - kLeafCountBits));
 
-    // inner nodes get consecutive ids in DFS order
+    // inner nodes get their record index from the storage order (depth-first pre-order by default)
+    const std::vector<int32_t> order = node_storage_order(t, layout & 15u);
     std::vector<int32_t> inner_id(t.nodes.size(), -1);
-    uint32_t n_inner = 0;
+    const uint32_t n_inner = (uint32_t)order.size();
+    for (uint32_t k = 0; k < n_inner; k++)
+        if (order[k] >= 0) inner_id[(size_t)order[k]] = (int32_t)k;
     for (size_t i = 0; i < t.nodes.size(); i++)
-        if (!t.nodes[i].is_leaf) inner_id[i] = (int32_t)n_inner++;
+        if (!t.nodes[i].is_leaf && inner_id[i] < 0) return fail(MR_ERR_STATE, "node %zu missing from the storage order", i);
+
+    // leaves: where each one's triangles start in the record array.  MR_LAYOUT_ALIGN_LEAVES puts up to seven unused
+    // 48-byte records in front of a leaf when that lowers the number of 128-byte lines its triangles touch.
+    std::vector<uint32_t> leaf_first(t.nodes.size(), 0);
+    uint32_t n_rec = 0;
+    {
+        std::vector<uint32_t> leaves;
+        for (size_t i = 0; i < t.nodes.size(); i++)
+            if (t.nodes[i].is_leaf) leaves.push_back((uint32_t)i);
+        std::sort(leaves.begin(), leaves.end(), [&](uint32_t x, uint32_t y) { return t.nodes[x].a < t.nodes[y].a; });
+        for (uint32_t li : leaves) {
+            const uint32_t cnt = (uint32_t)t.nodes[li].b;
+            if ((layout & MR_LAYOUT_ALIGN_LEAVES) && cnt > 0 && cnt <= 8) {
+                const auto lines = [&](uint32_t first) { return (first * 48u + cnt * 48u - 1u) / 128u - (first * 48u) / 128u + 1u; };
+                uint32_t best = 0;
+                for (uint32_t pad = 1; pad < 8; pad++)
+                    if (lines(n_rec + pad) < lines(n_rec + best)) best = pad;
+                n_rec += best;
+            }
+            leaf_first[li] = n_rec;
+            n_rec += cnt;
+        }
+    }
+    if (n_rec >= (1u << (31 - kLeafCountBits))) return fail(MR_ERR_INVALID, "padded triangle array exceeds the leaf reference encoding");
     auto ref_of = [&](int32_t node) -> int32_t {
         const HostNode &nd = t.nodes[(size_t)node];
-        return nd.is_leaf ? leaf_ref((uint32_t)nd.a, (uint32_t)nd.b) : inner_id[(size_t)node];
+        return nd.is_leaf ? leaf_ref(leaf_first[(size_t)node], (uint32_t)nd.b) : inner_id[(size_t)node];
     };
 
-    std::vector<float4> nodes((size_t)n_inner * 4);
+    std::vector<float4> nodes((size_t)n_inner * 4, make_float4(0.f, 0.f, 0.f, 0.f));
     for (size_t i = 0; i < t.nodes.size(); i++) {
         const HostNode &nd = t.nodes[i];
         if (nd.is_leaf) continue;
@@ -109,38 +201,43 @@ mr_status flatten_and_upload(mr_scene *s) {
     }
 
     // triangles pre-gathered in leaf order: A, B-A, C-A, (B-A)x(C-A)  (Triangle.cpp:143-151)
-    std::vector<float4> tris((size_t)nt * 3);
-    std::vector<uint32_t> cnt_ext(nt, 0);
-    for (uint32_t k = 0; k < nt; k++) {
-        const uint32_t prim = t.leaf_prims[k];
-        if (m.is_sphere(prim)) {
-            const float *sp = &m.spheres[4 * (size_t)m.vi[3 * (size_t)prim + 1]];
-            uint32_t tag = kSphereTag;
-            float tagf;
-            memcpy(&tagf, &tag, sizeof(tagf));
-            tris[3 * (size_t)k + 0] = make_float4(sp[0], sp[1], sp[2], sp[3]);
-            tris[3 * (size_t)k + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
-            tris[3 * (size_t)k + 2] = make_float4(0.f, 0.f, 0.f, tagf);
-            continue;
+    std::vector<float4> tris((size_t)n_rec * 3, make_float4(0.f, 0.f, 0.f, 0.f));
+    std::vector<uint32_t> cnt_ext(n_rec, 0), rec_prim(n_rec, MR_MISS);
+    for (size_t li = 0; li < t.nodes.size(); li++) {
+        const HostNode &leaf = t.nodes[li];
+        if (!leaf.is_leaf) continue;
+        for (int32_t j = 0; j < leaf.b; j++) {
+            const uint32_t k = leaf_first[li] + (uint32_t)j;
+            const uint32_t prim = t.leaf_prims[(size_t)leaf.a + (size_t)j];
+            rec_prim[k] = prim;
+            if (m.is_sphere(prim)) {
+                const float *sp = &m.spheres[4 * (size_t)m.vi[3 * (size_t)prim + 1]];
+                uint32_t tag = kSphereTag;
+                float tagf;
+                memcpy(&tagf, &tag, sizeof(tagf));
+                tris[3 * (size_t)k + 0] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                tris[3 * (size_t)k + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                tris[3 * (size_t)k + 2] = make_float4(0.f, 0.f, 0.f, tagf);
+                continue;
+            }
+            const float *A = &m.v[3 * (size_t)m.vi[3 * prim]];
+            const float *B = &m.v[3 * (size_t)m.vi[3 * prim + 1]];
+            const float *C = &m.v[3 * (size_t)m.vi[3 * prim + 2]];
+            const float bx = B[0] - A[0], by = B[1] - A[1], bz = B[2] - A[2];
+            const float cx = C[0] - A[0], cy = C[1] - A[1], cz = C[2] - A[2];
+            const float nx = by * cz - bz * cy, ny = bz * cx - bx * cz, nz = bx * cy - by * cx;
+            tris[3 * (size_t)k + 0] = make_float4(A[0], A[1], A[2], bx);
+            tris[3 * (size_t)k + 1] = make_float4(by, bz, cx, cy);
+            tris[3 * (size_t)k + 2] = make_float4(cz, nx, ny, nz);
         }
-        const float *A = &m.v[3 * (size_t)m.vi[3 * prim]];
-        const float *B = &m.v[3 * (size_t)m.vi[3 * prim + 1]];
-        const float *C = &m.v[3 * (size_t)m.vi[3 * prim + 2]];
-        const float bx = B[0] - A[0], by = B[1] - A[1], bz = B[2] - A[2];
-        const float cx = C[0] - A[0], cy = C[1] - A[1], cz = C[2] - A[2];
-        const float nx = by * cz - bz * cy, ny = bz * cx - bx * cz, nz = bx * cy - by * cx;
-        tris[3 * (size_t)k + 0] = make_float4(A[0], A[1], A[2], bx);
-        tris[3 * (size_t)k + 1] = make_float4(by, bz, cx, cy);
-        tris[3 * (size_t)k + 2] = make_float4(cz, nx, ny, nz);
+        if (leaf.b >= kLeafCountMask && leaf.b > 0) cnt_ext[(size_t)leaf_first[li]] = (uint32_t)leaf.b;
     }
-    for (const HostNode &nd : t.nodes)
-        if (nd.is_leaf && nd.b >= kLeafCountMask) cnt_ext[(size_t)nd.a] = (uint32_t)nd.b;
 
     d.bytes = 0;
     mr_status st;
     if ((st = upload(d.nodes, nodes.data(), nodes.size(), d.bytes)) != MR_OK) return st;
     if ((st = upload(d.tris, tris.data(), tris.size(), d.bytes)) != MR_OK) return st;
-    if ((st = upload(d.tri_prim, t.leaf_prims.data(), t.leaf_prims.size(), d.bytes)) != MR_OK) return st;
+    if ((st = upload(d.tri_prim, rec_prim.data(), rec_prim.size(), d.bytes)) != MR_OK) return st;
     if ((st = upload(d.leaf_cnt_ext, cnt_ext.data(), cnt_ext.size(), d.bytes)) != MR_OK) return st;
     if ((st = upload(d.v, m.v.data(), m.v.size(), d.bytes)) != MR_OK) return st;
     if ((st = upload(d.n, m.n.data(), m.n.size(), d.bytes)) != MR_OK) return st;
@@ -169,7 +266,7 @@ mr_status flatten_and_upload(mr_scene *s) {
     memcpy(d.root_hi, root.hi, sizeof(d.root_hi));
     d.root_ref = ref_of(0);
     d.n_inner = n_inner;
-    d.n_tris = nt;
+    d.n_tris = n_rec;
     d.stack_depth = t.max_depth + 1;   // pending far children (one per inner node on a root-to-leaf path, <= max_depth) + the kDone sentinel
     MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&s->d_stats), 2 * sizeof(unsigned long long)));
     MR_HIP_CHECK(hipMemset(s->d_stats, 0, 2 * sizeof(unsigned long long)));
@@ -365,7 +462,10 @@ mr_status mr_bvh_build(mr_scene *s, const mr_build_opts *opts) {
     if (st != MR_OK) return st;
     s->built = true;
     if (host_only) return MR_OK;
-    st = flatten_and_upload(s);
+    const uint32_t layout = opts ? opts->layout : 0u;
+    if ((layout & 15u) > MR_LAYOUT_TREELETS || (layout & ~(uint32_t)(15u | MR_LAYOUT_ALIGN_LEAVES)))
+        return fail(MR_ERR_INVALID, "unknown layout %u", layout);
+    st = flatten_and_upload(s, layout);
     if (st != MR_OK) { release_device(s); return st; }
     s->on_device = true;
     return MR_OK;

@@ -197,7 +197,7 @@ constexpr int kKnnMaxK = 512;     // nphotons limit of the wave-cooperative k-NN
 mr_status launch_irradiance(const PhotonMapDev &pm, const float *d_pos, const float *d_normal, unsigned long long nq,
                             float max_dist, uint32_t k, float *d_irrad, int32_t *d_found, float *d_r2, unsigned long long *d_stats,
                             hipStream_t stream);
-constexpr int kPhotonStats = 6;   // queries, blocks, records examined by the search, tightenings, pre-pass records, repeated searches
+constexpr int kPhotonStats = 12;  // see mr_photon_map_get_stats (miro_hip.h)
 
 }  // namespace mr
 

@@ -279,7 +279,7 @@ mr_status mr_photon_map_count_stats(mr_photon_map *m, int32_t enable) {
     return MR_OK;
 }
 
-mr_status mr_photon_map_get_stats(mr_photon_map *m, uint64_t out[6], int32_t reset) {
+mr_status mr_photon_map_get_stats(mr_photon_map *m, uint64_t out[12], int32_t reset) {
     if (!m || !out) return fail(MR_ERR_INVALID, "NULL argument");
     if (!m->d_stats) return fail(MR_ERR_STATE, "mr_photon_map_count_stats has not been enabled on this map");
     MR_HIP_CHECK(hipSetDevice(m->device));

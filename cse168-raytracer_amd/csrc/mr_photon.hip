@@ -33,18 +33,38 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr int kCap = 704;          // candidate slots per wave: kTighten + one block of 63 candidates + 1
-constexpr int kStack = 256;        // pending block roots per wave: <= 64 per block level, 4 block levels = 24 tree levels (checked at launch)
 constexpr int kTighten = 640;      // compress (tighten the radius) once this many candidates are buffered
+#ifndef MIRO_PHOTON_GUESS_MARGIN
+#define MIRO_PHOTON_GUESS_MARGIN 1.02f
+#endif
+constexpr float kGuessMargin = MIRO_PHOTON_GUESS_MARGIN;   // on the guessed squared radius (see the kernel)
 
+// A wave's LDS (dynamic, sized at launch): the candidate buffer, the stack of pending block roots -- an expanded block
+// leaves at most 64 roots of the next layer of blocks pending and the newest are popped first, so 64 x (layers - 1)
+// entries: 128 for up to 2^18 photons instead of a fixed 256 -- and the radix-select histogram, which shares its words
+// with the child slots of the push phase (the two are never live together).  7 680 bytes per wave for a 200 000-photon
+// map: five waves per SIMD where the fixed 9 216-byte layout allowed four.
 struct WaveLds {
-    float d2[kCap];
-    int idx[kCap];
-    int stack[kStack];
-    float lb[kStack];        // per pending block: squared distance of the farthest plane crossed on the far side
-    unsigned hist[256];
-    int slot[64];            // children of one block, indexed by visiting-order key
-    float slot_lb[64];
+    float *d2;               // [kCap]
+    int *idx;                // [kCap]
+    unsigned *hist;          // [256]
+    int *slot;               // [64]   children of one block, indexed by visiting-order key   (= hist)
+    float *slot_lb;          // [64]                                                           (= hist + 64)
+    int *stack;              // [stack_cap] pending block roots
+    float *lb;               // [stack_cap] per pending block: squared distance of the farthest plane crossed on the far side
 };
+__host__ __device__ inline int wave_lds_words(int stack_cap) { return 2 * kCap + 256 + 2 * stack_cap; }
+__device__ __forceinline__ WaveLds wave_lds(int *base, int stack_cap) {
+    WaveLds w;
+    w.d2 = reinterpret_cast<float *>(base);
+    w.idx = base + kCap;
+    w.hist = reinterpret_cast<unsigned *>(base + 2 * kCap);
+    w.slot = base + 2 * kCap;
+    w.slot_lb = reinterpret_cast<float *>(base + 2 * kCap + 64);
+    w.stack = base + 2 * kCap + 256;
+    w.lb = reinterpret_cast<float *>(base + 2 * kCap + 256 + stack_cap);
+    return w;
+}
 
 // a cross-lane hand-off through wave-private LDS: release + acquire at wavefront scope and a wave barrier, so that neither
 // the compiler nor the memory model may move LDS accesses across it (no instruction is emitted beyond a waitcnt)
@@ -56,7 +76,7 @@ __device__ __forceinline__ void lds_handoff() {
 
 // k-th smallest (1-based rank `k`) of d2[0..count): returns its bit pattern and how many entries equal to it belong
 // to the k smallest.  Non-negative floats order like their bit patterns.
-__device__ __forceinline__ unsigned radix_select(WaveLds &w, int count, int k, int lane, int &eq_keep) {
+__device__ __forceinline__ unsigned radix_select(const WaveLds &w, int count, int k, int lane, int &eq_keep) {
     unsigned prefix = 0;
     int remaining = k;
     for (int shift = 24; shift >= 0; shift -= 8) {
@@ -96,7 +116,7 @@ __device__ __forceinline__ unsigned radix_select(WaveLds &w, int count, int k, i
 }
 
 // keep the k smallest candidates at the front of the buffer; returns the k-th distance
-__device__ __forceinline__ float compress(WaveLds &w, int &count, int k, int lane) {
+__device__ __forceinline__ float compress(const WaveLds &w, int &count, int k, int lane) {
     int eq_keep;
     const unsigned kth = radix_select(w, count, k, lane, eq_keep);
     int out = 0, eq_seen = 0;
@@ -191,10 +211,10 @@ __device__ __forceinline__ int first_overflow(const PhotonMapDev &pm, float qx, 
 template <bool STATS>
 __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, const float *qpos, const float *qnrm,
                                                             unsigned long long nq, float max_dist, int k, float *irrad,
-                                                            int *found_out, float *r2_out, unsigned long long *stats) {
-    __shared__ WaveLds s_w[kWaves];
+                                                            int *found_out, float *r2_out, unsigned long long *stats, int stack_cap) {
+    extern __shared__ int s_lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    WaveLds &w = s_w[wv];
+    const WaveLds w = wave_lds(s_lds + wv * wave_lds_words(stack_cap), stack_cap);
     const unsigned long long wave_id = (unsigned long long)blockIdx.x * kWaves + wv;
     const unsigned long long n_waves = (unsigned long long)gridDim.x * kWaves;
     // node of this lane inside a block: level lv (0..5), offset within the level
@@ -204,6 +224,7 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
 
     const float md2 = max_dist * max_dist;
     unsigned long long st_queries = 0, st_blocks = 0, st_records = 0, st_tighten = 0, st_prepass = 0, st_retries = 0;
+    unsigned long long st_reached = 0, st_cands = 0, st_top = 0, st_mid = 0, st_unguessed = 0;
     // a wave takes 64 consecutive queries at a time: first every lane finds its own query's m* (first_overflow), then
     // the wave searches the 64 queries one after the other
     for (unsigned long long base = wave_id * 64ull; base < nq; base += n_waves * 64ull) {
@@ -255,12 +276,12 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
         if (prev_ok && mstar != 0) {
             float dx = qx - pqx, dy = qy - pqy, dz = qz - pqz;
             const float g = sqrtf(prev_r2) + sqrtf((dx * dx + dy * dy) + dz * dz);
-            const float g2 = (g * g) * 1.0001f;               // strictly beyond the would-be k-th photon; only a guess anyway
+            const float g2 = (g * g) * kGuessMargin;               // strictly beyond the would-be k-th photon; only a guess anyway
             if (g2 < safe_r2) { r2 = g2; guessed = true; }
         }
         int count;
         bool evicted;
-        if (STATS) st_queries++;
+        if (STATS) { st_queries++; if (!guessed) st_unguessed++; }
       search_again:
         count = 0;
         evicted = false;
@@ -280,7 +301,7 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
             const int j = valid ? jj : 0;
             float4 A = make_float4(0.f, 0.f, 0.f, 0.f), D = make_float4(0.f, 0.f, 0.f, 0.f);
             if (valid) { A = pm.posplane[j]; D = pm.dir[j]; }
-            if (STATS) { st_blocks++; st_records += (unsigned)__popcll(__ballot(valid)); }
+            if (STATS) { st_blocks++; st_records += (unsigned)__popcll(__ballot(valid)); if (b < 64) st_top++; else if (b < 4096) st_mid++; }
             const int plane = __float_as_int(A.w);
             const float pc = plane == 0 ? A.x : (plane == 1 ? A.y : A.z);
             const float qc = plane == 0 ? qx : (plane == 1 ? qy : qz);
@@ -327,6 +348,7 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
                 w.d2[pos] = d2; w.idx[pos] = j;
             }
             count += __popcll(mc);
+            if (STATS) { st_reached += (unsigned)__popcll(__ballot(reach)); st_cands += (unsigned)__popcll(mc); }
             // children of the level-5 nodes become block roots, pushed so that they pop in the reference's order:
             // key = far-step bits of the whole path (6 bits, unique per child); slot[key] is filled by its owner,
             // then lane `key` moves it to the stack behind all larger keys.  A block whose level-5 nodes do not descend
@@ -398,6 +420,8 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
     if (STATS && lane == 0 && stats) {
         atomicAdd(&stats[0], st_queries); atomicAdd(&stats[1], st_blocks); atomicAdd(&stats[2], st_records);
         atomicAdd(&stats[3], st_tighten); atomicAdd(&stats[4], st_prepass); atomicAdd(&stats[5], st_retries);
+        atomicAdd(&stats[6], st_reached); atomicAdd(&stats[7], st_cands); atomicAdd(&stats[8], st_top); atomicAdd(&stats[9], st_mid);
+        atomicAdd(&stats[10], st_unguessed);
     }
 }
 
@@ -408,15 +432,20 @@ mr_status launch_irradiance(const PhotonMapDev &pm, const float *d_pos, const fl
                             hipStream_t stream) {
     static_assert(kTighten + 64 <= kCap && kKnnMaxK <= kTighten, "candidate buffer must hold k plus one block");
     if (pm.n >= (1 << 24))
-        return fail(MR_ERR_INVALID, "photon maps of 2^24 photons or more need a deeper block stack (kStack)");
+        return fail(MR_ERR_INVALID, "photon maps of 2^24 photons or more need a fifth layer of blocks");
+    // layers of 6-level blocks that hold nodes; an expanded block leaves at most 64 roots of the next layer pending
+    int layers = 1;
+    while (layers < 4 && (1ll << (6 * layers)) <= (long long)pm.n) layers++;
+    const int stack_cap = layers > 1 ? 64 * (layers - 1) : 64;
+    const size_t lds = (size_t)kWaves * wave_lds_words(stack_cap) * sizeof(int);
     unsigned long long blocks = (nq + kWaves - 1) / kWaves;
-    if (blocks > 256ull * 16ull) blocks = 256ull * 16ull;
+    if (blocks > 256ull * 20ull) blocks = 256ull * 20ull;
     if (d_stats)
-        hipLaunchKernelGGL(irradiance_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, pm, d_pos, d_normal, nq, max_dist,
-                           (int)k, d_irrad, d_found, d_r2, d_stats);
+        hipLaunchKernelGGL(irradiance_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), lds, stream, pm, d_pos, d_normal, nq, max_dist,
+                           (int)k, d_irrad, d_found, d_r2, d_stats, stack_cap);
     else
-        hipLaunchKernelGGL(irradiance_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, pm, d_pos, d_normal, nq, max_dist,
-                           (int)k, d_irrad, d_found, d_r2, d_stats);
+        hipLaunchKernelGGL(irradiance_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds, stream, pm, d_pos, d_normal, nq, max_dist,
+                           (int)k, d_irrad, d_found, d_r2, d_stats, stack_cap);
     MR_HIP_CHECK(hipGetLastError());
     return MR_OK;
 }

@@ -27,6 +27,7 @@ MR_FRAME_NO_SHADOWS = 1 << 8
 
 MR_PATH_MIRROR, MR_PATH_REFRACT, MR_PATH_DIFFUSE = 1, 2, 4
 MR_LEVEL_LAST, MR_LEVEL_SPECULAR, MR_LEVEL_PATH = 0, 1, 2
+MR_LAYOUT_DFS, MR_LAYOUT_PAIRS, MR_LAYOUT_TREELETS, MR_LAYOUT_ALIGN_LEAVES = 0, 1, 2, 16
 
 MR_OK, MR_ERR_INVALID, MR_ERR_IO, MR_ERR_NOMEM, MR_ERR_HIP, MR_ERR_STATE = 0, -1, -2, -3, -4, -5
 
@@ -61,7 +62,7 @@ class MeshDesc(C.Structure):
 
 class BuildOpts(C.Structure):
     _fields_ = [("leaf_size", C.c_uint32), ("builder", C.c_uint32), ("host_only", C.c_uint32),
-                ("reserved", C.c_uint32 * 5)]
+                ("layout", C.c_uint32), ("reserved", C.c_uint32 * 4)]
 
 
 class SceneInfo(C.Structure):
@@ -319,11 +320,13 @@ class Scene:
         return len(vi)
 
     # ---- Scene::preCalc -> BVH::build (Scene.cpp:72)
-    def build(self, leaf_size=4, host_only=False):
+    def build(self, leaf_size=4, host_only=False, layout=None):
+        """layout: MR_LAYOUT_* (storage order of the device records; default from MIRO_LAYOUT for A/B probes, else 0)"""
         o = BuildOpts()
         o.leaf_size = leaf_size
         o.builder = 0
         o.host_only = 1 if host_only else 0
+        o.layout = int(os.environ.get("MIRO_LAYOUT", "0")) if layout is None else layout
         _check(self.L.mr_bvh_build(self.h, C.byref(o)))
         return self.info()
 
@@ -559,7 +562,8 @@ class PhotonMap:
                                              d_irrad.data_ptr(), d_found.data_ptr() if d_found is not None else None,
                                              d_r2.data_ptr() if d_r2 is not None else None, _stream_ptr(stream)))
 
-    STAT_NAMES = ("queries", "blocks", "records_searched", "tightenings", "records_prepass", "repeated_searches")
+    STAT_NAMES = ("queries", "blocks", "records_searched", "tightenings", "records_prepass", "repeated_searches", "reached",
+                  "candidates", "blocks_top", "blocks_mid", "unguessed", "unused")
 
     def count_stats(self, enable=True):
         """mr_photon_map_count_stats: the estimates on this map run the counting build of the kernel while enabled."""
@@ -567,6 +571,6 @@ class PhotonMap:
 
     def stats(self, reset=True):
         """mr_photon_map_get_stats as a dict (synchronises the device)."""
-        out = (C.c_uint64 * 6)()
+        out = (C.c_uint64 * 12)()
         _check(self.L.mr_photon_map_get_stats(self.h, out, 1 if reset else 0))
         return dict(zip(self.STAT_NAMES, (int(v) for v in out)))

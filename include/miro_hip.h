@@ -64,9 +64,18 @@ typedef struct mr_build_opts {
     uint32_t builder;       /* MR_BUILD_REFERENCE (0): the reference's binary-search split, identical tree */
     uint32_t host_only;     /* 1: build the tree on the host and skip the device upload (tree inspection,
                                CPU-only tooling); mr_trace on such a scene fails with MR_ERR_STATE */
-    uint32_t reserved[5];
+    uint32_t layout;        /* storage order of the device records (MR_LAYOUT_*): a permutation of where the same nodes and
+                               triangles live in HBM -- references, visiting order and hit records are unaffected */
+    uint32_t reserved[4];
 } mr_build_opts;
 enum { MR_BUILD_REFERENCE = 0 };
+enum {
+    MR_LAYOUT_DFS      = 0,   /* inner nodes in depth-first pre-order (a node's first inner child is its neighbour) */
+    MR_LAYOUT_PAIRS    = 1,   /* pre-order, padded so that a node and its first inner child always share one 128-byte line */
+    MR_LAYOUT_TREELETS = 2,   /* the top 12 levels breadth-first, below them treelets of three levels stored contiguously */
+    MR_LAYOUT_ALIGN_LEAVES = 16 /* OR-ed in: dummy triangle records in front of a leaf whenever that lets its triangles touch
+                                   fewer 128-byte lines */
+};
 
 typedef struct mr_scene_info {
     uint32_t n_vertices, n_normals, n_triangles;
@@ -360,9 +369,11 @@ mr_status mr_irradiance_estimate(mr_photon_map *map, const float *d_pos, const f
  * the counting build of the kernel and adds to: [0] queries answered, [1] blocks of 63 kd-tree nodes expanded, [2] photon
  * records (position + direction, 32 bytes) examined by the search, [3] radius tightenings (k-th-nearest selections),
  * [4] photon records examined by the reference-order pre-pass that finds the first overflow's victim
- * (PhotonMap.cpp:195-240), [5] searches repeated because a guessed radius did not hold the k nearest. */
+ * (PhotonMap.cpp:195-240), [5] searches repeated because a guessed radius did not hold the k nearest, [6] nodes the
+ * reference's pruning rule reaches inside the expanded blocks, [7] candidates buffered, [8] / [9] expanded blocks among the top
+ * 6 / the next 6 tree levels, [10] queries searched from the pre-pass's safe radius (no guess available), [11] unused. */
 mr_status mr_photon_map_count_stats(mr_photon_map *map, int32_t enable);
-mr_status mr_photon_map_get_stats(mr_photon_map *map, uint64_t counters[6], int32_t reset);
+mr_status mr_photon_map_get_stats(mr_photon_map *map, uint64_t counters[12], int32_t reset);
 
 /* The photon-map term of Scene::traceScene (Scene.cpp:285-299) for a traced batch: for every ray whose hit has a
  * diffuse material (Phong::isDiffuse), irradiance_estimate on the global and on the caustic map (either may be NULL)

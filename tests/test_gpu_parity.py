@@ -600,3 +600,40 @@ def test_bunny20_published_totals(oracle, miro, torch_cuda):
     assert_hits_bit_exact(b.trace(sh.view(miro.RAY_DTYPE)), want_s.view(miro.HIT_DTYPE))
     b.trace(sh.view(miro.RAY_DTYPE), flags=miro.MR_COUNT_STATS)
     assert b.stats() == ctr_s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", [1, 2, 16, 17, 18])
+def test_storage_layouts_give_identical_hit_records(miro, layout):
+    """mr_build_opts.layout permutes WHERE node and triangle records live in HBM (pair-aligned pre-order, breadth-first top +
+    treelets, leaves padded to fewer 128-byte lines); references, visiting order and therefore every hit record are those of
+    the default order -- on camera rays and on random rays, default, voting and counting kernels, triangle and sphere scenes."""
+    import torch
+    from miro_amd import scenes as sc_mod
+    for name in ("sponza", "spiral", "cornell"):
+        d = sc_mod.SCENES[name]
+        built = []
+        for lay in (0, layout):
+            s = miro.Scene(0)
+            sc_mod.populate(s, d)
+            s.build(4, layout=lay)
+            built.append(s)
+        W, H = 160, 90
+        n = W * H
+        cam = miro.binding.make_camera(d["eye"], d["lookat"], d["up"], d["fov"])
+        rays = torch.empty((n, 8), dtype=torch.float32, device="cuda")
+        built[0].gen_eye_rays(cam, W, H, rays)
+        v = built[0].arrays()[0]
+        rnd = random_rays(miro.RAY_DTYPE, 20000, v.min(0), v.max(0), seed=3)
+        d_rnd = torch.from_numpy(rnd.view(np.float32).reshape(-1, 8)).cuda()
+        for batch, m in ((rays, n), (d_rnd, len(rnd))):
+            for flags in (0, miro.MR_TRACE_INCOHERENT, miro.MR_COUNT_STATS, miro.MR_MATH_PRODUCT, miro.MR_TRACE_PERSISTENT):
+                outs = []
+                for s in built:
+                    o = torch.empty((m, 4), dtype=torch.float32, device="cuda")
+                    s.trace_device(batch, m, o, flags)
+                    torch.cuda.synchronize()
+                    outs.append(o.cpu().numpy().tobytes())
+                    if flags == miro.MR_COUNT_STATS:
+                        outs[-1] += repr(s.stats()).encode()
+                assert outs[0] == outs[1], (name, flags)

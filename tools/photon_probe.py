@@ -42,3 +42,10 @@ e1.record(st); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.reps
 print("%d queries, k=%d: %.2f ms  %.2f Mqueries/s  (found min %d max %d, mean irradiance %.4g)" %
       (nq, a.k, ms, nq / ms / 1e3, int(fnd.min()), int(fnd.max()), float(out.mean())))
+import zlib
+print("checksums: irradiance %08x found %08x" % (zlib.crc32(out.cpu().numpy().tobytes()), zlib.crc32(fnd.cpu().numpy().tobytes())))
+pm.count_stats(True)
+pm.irradiance_estimate(P, N, nq, out, nphotons=a.k, stream=st)
+w = pm.stats()
+pm.count_stats(False)
+print("per query: " + "  ".join("%s %.2f" % (k, v / nq) for k, v in w.items() if k != "unused"))

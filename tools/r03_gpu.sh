@@ -23,5 +23,14 @@ case $stage in
   photon)
     python -m pytest tests/test_photon.py -x -q -m gpu > $out/pytest.log 2>&1; echo "pytest rc=$?" >> $out/pytest.log; tail -n 4 $out/pytest.log
     python bench.py --config photon > $out/photon.json 2> $out/photon.err; cat $out/photon.json; tail -n 3 $out/photon.err ;;
+  photon_ab)
+    for v in ${PHOTON_VARIANTS:-default _nopf default _nopf}; do
+      d=lib$v; [ "$v" = default ] && d=lib
+      echo "== $d" >> $out/photon_ab.log
+      MIRO_LIB=$LIB/$d/libmiro_hip.so python tools/photon_probe.py $PHOTON_ARGS >> $out/photon_ab.log 2>&1
+    done; grep -v amdgpu.ids $out/photon_ab.log ;;
+  layouts)
+    python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k layouts > $out/pytest.log 2>&1; echo "pytest rc=$?" >> $out/pytest.log; tail -n 4 $out/pytest.log
+    python tools/layout_probe.py > $out/layout_probe.log 2>&1; grep -v amdgpu.ids $out/layout_probe.log ;;
   *) echo "unknown stage $stage"; exit 2 ;;
 esac
