@@ -208,8 +208,10 @@ __device__ __forceinline__ int first_overflow(const PhotonMapDev &pm, float qx, 
 // STATS: work counters of the launch, added to stats[0..5] (mr_photon_map_get_stats): queries answered, blocks expanded,
 // photon records examined by the cooperative search (32 bytes each: position + direction), radius tightenings,
 // photon records examined by the reference-order pre-pass, searches repeated with the safe radius.
+// Five waves per SIMD (96 registers) is what 7 680 bytes of LDS per wave allow; the fifth wave is worth 21 % (50.3 -> 41.5 ms),
+// so the register allocation is held to it.
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, const float *qpos, const float *qnrm,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void irradiance_kernel(PhotonMapDev pm, const float *qpos, const float *qnrm,
                                                             unsigned long long nq, float max_dist, int k, float *irrad,
                                                             int *found_out, float *r2_out, unsigned long long *stats, int stack_cap) {
     extern __shared__ int s_lds[];
@@ -351,7 +353,8 @@ __global__ __launch_bounds__(kBlock) void irradiance_kernel(PhotonMapDev pm, con
             if (STATS) { st_reached += (unsigned)__popcll(__ballot(reach)); st_cands += (unsigned)__popcll(mc); }
             // children of the level-5 nodes become block roots, pushed so that they pop in the reference's order:
             // key = far-step bits of the whole path (6 bits, unique per child); slot[key] is filled by its owner,
-            // then lane `key` moves it to the stack behind all larger keys.  A block whose level-5 nodes do not descend
+            // then lane `key` moves it to the stack behind all larger keys.  (Computing path / lb only in blocks that push was measured:
+            // 43.5 vs 41.5 ms -- the shuffled distances stay live longer.)  A block whose level-5 nodes do not descend
             // (b * 32 >= half: the bottom layer of blocks, most of those a query touches) has nothing to push.
             if ((b << 5) < pm.half) {
                 lds_handoff();                                // candidate append above / slot reuse below

@@ -32,5 +32,54 @@ case $stage in
   layouts)
     python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k layouts > $out/pytest.log 2>&1; echo "pytest rc=$?" >> $out/pytest.log; tail -n 4 $out/pytest.log
     python tools/layout_probe.py > $out/layout_probe.log 2>&1; grep -v amdgpu.ids $out/layout_probe.log ;;
+  layout_pmc)
+    # L1 accesses / L2 requests per ray of the random-ray launch under three storage orders
+    export TMPDIR=/tmp
+    for lay in 0 2 18; do
+      export MIRO_LAYOUT=$lay
+      rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/lay$lay -- \
+        python3 tools/pmc_probe.py --what random --flags 0 > $out/lay$lay.log 2>&1
+    done
+    unset MIRO_LAYOUT
+    python3 - <<'PY'
+import csv, glob, re
+for lay in (0, 2, 18):
+    d = "gpurun_out/r03_layout_pmc/lay%d" % lay
+    log = open(d + ".log", errors="replace").read()
+    m = re.search(r"PMC_PROBE.*rays=(\d+).*ms=([0-9.]+) mrays_s=([0-9.]+)", log)
+    acc = {}
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "trace_kernel" in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    rays = int(m.group(1)) if m else 1
+    mean = {k: sum(v) / len(v) for k, v in acc.items()}
+    print("layout %2d: %s Mrays/s (under the profiler); per ray: L1 accesses %.2f  L2 read requests %.2f  L2 hit rate %.3f" % (
+        lay, m.group(3) if m else "?", mean.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0) / rays, mean.get("TCP_TCC_READ_REQ_sum", 0) / rays,
+        mean.get("TCC_HIT_sum", 0) / max(mean.get("TCC_HIT_sum", 0) + mean.get("TCC_MISS_sum", 0), 1)))
+PY
+    ;;
+  children_pmc)
+    export TMPDIR=/tmp
+    rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 tools/bounce_probe.py > $out/trace.log 2>&1
+    rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAVES --output-format csv -d $out/pmc1 -- python3 tools/bounce_probe.py > $out/pmc1.log 2>&1
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc2 -- python3 tools/bounce_probe.py > $out/pmc2.log 2>&1
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc3 -- python3 tools/bounce_probe.py > $out/pmc3.log 2>&1
+    python3 - <<'PY'
+import csv, glob, collections
+for d in ("pmc1", "pmc2", "pmc3"):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob("gpurun_out/r03_children_pmc/%s/**/*counter_collection.csv" % d, recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "children_kernel" in k or "trace_kernel" in k:
+                acc[k[:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, c in acc.items():
+        print(d, k, {n: "%.4g" % (sum(v) / len(v)) for n, v in c.items()}, "dispatches", max(len(v) for v in c.values()))
+for f in glob.glob("gpurun_out/r03_children_pmc/trace/**/*kernel_stats.csv", recursive=True):
+    for i, r in enumerate(csv.reader(open(f))):
+        if i < 8: print(r[:6])
+PY
+    ;;
   *) echo "unknown stage $stage"; exit 2 ;;
 esac
