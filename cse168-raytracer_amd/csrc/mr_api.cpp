@@ -818,30 +818,32 @@ mr_status mr_shade_accumulate(mr_scene *s, const mr_ray *d_rays, const mr_hit *d
 
 mr_status mr_gen_secondary_rays(mr_scene *s, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
                                 const uint32_t *d_pixels, uint64_t n, uint32_t spp, mr_ray *d_out_rays, float *d_out_weights,
-                                uint32_t *d_out_pixels, uint64_t *d_count, void *stream) {
+                                uint32_t *d_out_pixels, uint64_t *d_count, uint64_t out_capacity, void *stream) {
     mr_status st = require_device(s);
     if (st != MR_OK) return st;
     if (!d_rays || !d_hits || !d_out_rays || !d_out_weights || !d_out_pixels || !d_count) return fail(MR_ERR_INVALID, "NULL argument");
     if (spp == 0) return fail(MR_ERR_INVALID, "spp is 0");
     if (n / spp > 0xFFFFFFFFull) return fail(MR_ERR_INVALID, "too many pixels");
+    if (out_capacity == 0 && n > 0) return fail(MR_ERR_INVALID, "mr_gen_secondary_rays: out_capacity is 0 (room for 3n rays always suffices)");
     MR_HIP_CHECK(hipSetDevice(s->device));
     return launch_secondary_rays(s->dev, d_rays, d_hits, d_weights, d_pixels, n, spp, d_out_rays, d_out_weights, d_out_pixels,
-                                 reinterpret_cast<unsigned long long *>(d_count), static_cast<hipStream_t>(stream));
+                                 reinterpret_cast<unsigned long long *>(d_count), out_capacity, static_cast<hipStream_t>(stream));
 }
 
 mr_status mr_gen_path_rays(mr_scene *s, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
                            const uint32_t *d_pixels, const uint32_t *d_ids, uint64_t n, uint32_t spp, uint32_t seed,
                            uint32_t bounce, uint32_t kinds, mr_ray *d_out_rays, float *d_out_weights, uint32_t *d_out_pixels,
-                           uint32_t *d_out_ids, uint64_t *d_count, void *stream) {
+                           uint32_t *d_out_ids, uint64_t *d_count, uint64_t out_capacity, void *stream) {
     mr_status st = require_device(s);
     if (st != MR_OK) return st;
     if (!d_rays || !d_hits || !d_out_rays || !d_out_weights || !d_out_pixels || !d_count) return fail(MR_ERR_INVALID, "NULL argument");
     if (spp == 0) return fail(MR_ERR_INVALID, "spp is 0");
     if (n / spp > 0xFFFFFFFFull || n > 0xFFFFFFFFull) return fail(MR_ERR_INVALID, "too many rays for 32-bit ray ids");
     if (kinds == 0 || (kinds & ~7u)) return fail(MR_ERR_INVALID, "kinds must be a combination of MR_PATH_MIRROR | MR_PATH_REFRACT | MR_PATH_DIFFUSE");
+    if (out_capacity == 0 && n > 0) return fail(MR_ERR_INVALID, "mr_gen_path_rays: out_capacity is 0 (room for 4n rays always suffices)");
     MR_HIP_CHECK(hipSetDevice(s->device));
     return launch_path_rays(s->dev, d_rays, d_hits, d_weights, d_pixels, d_ids, n, spp, seed, bounce, kinds, d_out_rays,
-                            d_out_weights, d_out_pixels, d_out_ids, reinterpret_cast<unsigned long long *>(d_count),
+                            d_out_weights, d_out_pixels, d_out_ids, reinterpret_cast<unsigned long long *>(d_count), out_capacity,
                             static_cast<hipStream_t>(stream));
 }
 
@@ -855,6 +857,8 @@ mr_status mr_trace_level(mr_scene *s, const mr_level_desc *level, const mr_ray *
     if (level->children > MR_LEVEL_PATH) return fail(MR_ERR_INVALID, "mr_trace_level: children must be MR_LEVEL_LAST, _SPECULAR or _PATH");
     if (level->children != MR_LEVEL_LAST && (!d_out_rays || !d_out_weights || !d_out_pixels || !d_out_count))
         return fail(MR_ERR_INVALID, "mr_trace_level: a level with children needs the output queue");
+    if (level->children != MR_LEVEL_LAST && n > 0 && level->out_capacity_lo == 0 && level->out_capacity_hi == 0)
+        return fail(MR_ERR_INVALID, "mr_trace_level: out_capacity is 0 (room for %un rays always suffices)", level->children == MR_LEVEL_PATH ? 4u : 3u);
     if (level->spp == 0) return fail(MR_ERR_INVALID, "spp is 0");
     if (n > 0xFFFFFFFFull) return fail(MR_ERR_INVALID, "mr_trace_level: at most 2^32 - 1 rays per call");
     if (level->children == MR_LEVEL_PATH && (level->path_kinds == 0 || (level->path_kinds & ~7u)))

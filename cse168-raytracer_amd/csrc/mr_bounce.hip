@@ -101,8 +101,11 @@ struct BounceArgs {
 // 2 % of the time, nearly every wave still holds a hit, and the launch cost what the dense first level costs.
 constexpr int kGenIter = 8;
 
+#ifndef MIRO_CHILDREN_WAVES
+#define MIRO_CHILDREN_WAVES 5      /* 90 registers, no spill; unconstrained the scheduler took 160 (3 waves) for the same speed */
+#endif
 template <bool PATH>
-__global__ __launch_bounds__(kBlock) void children_kernel(BounceArgs a) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATH ? MIRO_CHILDREN_WAVES : 1, 8))) void children_kernel(BounceArgs a) {
     __shared__ unsigned s_list[kGenIter * kBlock];            // offsets into the chunk
     __shared__ unsigned s_cnt[kGenIter][kBlock / 64];
     __shared__ unsigned s_slot[kGenIter * kBlock];            // per listed ray: (children of earlier lanes of its wave << 3) | its own
@@ -257,13 +260,14 @@ mr_status launch_shade_accumulate(const DeviceScene &ds, const mr_ray *d_rays, c
 
 mr_status launch_secondary_rays(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
                                 const uint32_t *d_pixels, unsigned long long n, uint32_t spp, mr_ray *d_out_rays,
-                                float *d_out_weights, uint32_t *d_out_pixels, unsigned long long *d_count, hipStream_t stream) {
+                                float *d_out_weights, uint32_t *d_out_pixels, unsigned long long *d_count,
+                                unsigned long long out_capacity, hipStream_t stream) {
     MR_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), stream));
     if (n == 0) return MR_OK;
     BounceArgs a;
     a.m = mesh_of(ds); a.rays = d_rays; a.hits = d_hits; a.weights = d_weights; a.pixels = d_pixels; a.ids = nullptr;
     a.spp = spp; a.hbase = 0; a.bounce = 0; a.kinds = 0; a.n = n;
-    a.out.rays = d_out_rays; a.out.weights = d_out_weights; a.out.pixels = d_out_pixels; a.out.ids = nullptr; a.out.count = d_count;
+    a.out.rays = d_out_rays; a.out.weights = d_out_weights; a.out.pixels = d_out_pixels; a.out.ids = nullptr; a.out.count = d_count; a.out.capacity = out_capacity;
     hipLaunchKernelGGL(children_kernel<false>, dim3(grid_for((n + kGenIter - 1) / kGenIter)), dim3(kBlock), 0, stream, a);
     MR_HIP_CHECK(hipGetLastError());
     return MR_OK;
@@ -272,14 +276,14 @@ mr_status launch_secondary_rays(const DeviceScene &ds, const mr_ray *d_rays, con
 mr_status launch_path_rays(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
                            const uint32_t *d_pixels, const uint32_t *d_ids, unsigned long long n, uint32_t spp, uint32_t seed,
                            uint32_t bounce, uint32_t kinds, mr_ray *d_out_rays, float *d_out_weights, uint32_t *d_out_pixels,
-                           uint32_t *d_out_ids, unsigned long long *d_count, hipStream_t stream) {
+                           uint32_t *d_out_ids, unsigned long long *d_count, unsigned long long out_capacity, hipStream_t stream) {
     MR_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), stream));
     if (n == 0) return MR_OK;
     BounceArgs a;
     a.m = mesh_of(ds); a.rays = d_rays; a.hits = d_hits; a.weights = d_weights; a.pixels = d_pixels; a.ids = d_ids;
     a.spp = spp; a.bounce = bounce; a.kinds = kinds; a.n = n;
     a.hbase = pcg32(seed);
-    a.out.rays = d_out_rays; a.out.weights = d_out_weights; a.out.pixels = d_out_pixels; a.out.ids = d_out_ids; a.out.count = d_count;
+    a.out.rays = d_out_rays; a.out.weights = d_out_weights; a.out.pixels = d_out_pixels; a.out.ids = d_out_ids; a.out.count = d_count; a.out.capacity = out_capacity;
     hipLaunchKernelGGL(children_kernel<true>, dim3(grid_for((n + kGenIter - 1) / kGenIter)), dim3(kBlock), 0, stream, a);
     MR_HIP_CHECK(hipGetLastError());
     return MR_OK;

@@ -173,13 +173,14 @@ mr_status launch_shade_accumulate(const DeviceScene &ds, const mr_ray *d_rays, c
                                   uint32_t spp, float *d_rgb, hipStream_t stream);
 mr_status launch_secondary_rays(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
                                 const uint32_t *d_pixels, unsigned long long n, uint32_t spp, mr_ray *d_out_rays,
-                                float *d_out_weights, uint32_t *d_out_pixels, unsigned long long *d_count, hipStream_t stream);
+                                float *d_out_weights, uint32_t *d_out_pixels, unsigned long long *d_count,
+                                unsigned long long out_capacity, hipStream_t stream);
 
 // PATH_TRACING generators (mr_bounce.hip): kinds bit 0 mirror, 1 refraction pair, 2 diffuse bounce
 mr_status launch_path_rays(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
                            const uint32_t *d_pixels, const uint32_t *d_ids, unsigned long long n, uint32_t spp, uint32_t seed,
                            uint32_t bounce, uint32_t kinds, mr_ray *d_out_rays, float *d_out_weights, uint32_t *d_out_pixels,
-                           uint32_t *d_out_ids, unsigned long long *d_count, hipStream_t stream);
+                           uint32_t *d_out_ids, unsigned long long *d_count, unsigned long long out_capacity, hipStream_t stream);
 
 mr_status launch_level(const DeviceScene &ds, const mr_level_desc &ld, const mr_ray *d_rays, const float *d_weights,
                        const uint32_t *d_pixels, const uint32_t *d_ids, unsigned long long n, float *d_rgb, mr_ray *d_out_rays,

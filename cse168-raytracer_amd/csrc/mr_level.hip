@@ -202,6 +202,7 @@ mr_status launch_level(const DeviceScene &ds, const mr_level_desc &ld, const mr_
     a.spp = ld.spp; a.inv_spp = 1.0f / (float)ld.spp; a.hbase = pcg32(ld.seed); a.bounce = ld.bounce; a.kinds = ld.path_kinds;
     a.rgb = d_rgb;
     a.out.rays = d_out_rays; a.out.weights = d_out_weights; a.out.pixels = d_out_pixels; a.out.ids = d_out_ids; a.out.count = d_out_count;
+    a.out.capacity = ((unsigned long long)ld.out_capacity_hi << 32) | ld.out_capacity_lo;
     a.counts = d_counts;
 
     const bool product = ld.flags & MR_MATH_PRODUCT, vote = ld.flags & MR_TRACE_INCOHERENT;

@@ -211,7 +211,7 @@ __device__ __forceinline__ int first_overflow(const PhotonMapDev &pm, float qx, 
 // Five waves per SIMD (96 registers) is what 7 680 bytes of LDS per wave allow; the fifth wave is worth 21 % (50.3 -> 41.5 ms),
 // so the register allocation is held to it.
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void irradiance_kernel(PhotonMapDev pm, const float *qpos, const float *qnrm,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(STATS ? 4 : 5, 8))) void irradiance_kernel(PhotonMapDev pm, const float *qpos, const float *qnrm,
                                                             unsigned long long nq, float max_dist, int k, float *irrad,
                                                             int *found_out, float *r2_out, unsigned long long *stats, int stack_cap) {
     extern __shared__ int s_lds[];

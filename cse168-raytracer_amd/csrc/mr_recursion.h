@@ -309,6 +309,7 @@ struct ChildQueue {
     float *weights;
     uint32_t *pixels, *ids;       // ids may be NULL
     unsigned long long *count;
+    unsigned long long capacity;  // rays the arrays have room for: a child whose slot lies beyond is counted, not stored
 };
 
 // wave64 compaction: one ballot per child kind; the workgroup's waves share one atomic.  Called by all threads of the
@@ -326,8 +327,8 @@ __device__ __forceinline__ void write_children(const ChildQueue &q, const ChildG
     unsigned long long before = base;
 #pragma unroll
     for (int j = 0; j < NK; j++) {
-        if (emit[j]) {
-            const unsigned long long s = before + __popcll(mk[j] & lt);
+        const unsigned long long s = before + __popcll(mk[j] & lt);
+        if (emit[j] && s < q.capacity) {
             float org[3], dir[3], wgt[3];
             g.make(j, org, dir, wgt);
             reinterpret_cast<float4 *>(q.rays)[2 * s] = make_float4(org[0], org[1], org[2], 0.0f);
@@ -348,13 +349,15 @@ __device__ __forceinline__ void write_children_at(const ChildQueue &q, const Chi
 #pragma unroll
     for (int j = 0; j < NK; j++) {
         if (emit[j]) {
-            float org[3], dir[3], wgt[3];
-            g.make(j, org, dir, wgt);
-            reinterpret_cast<float4 *>(q.rays)[2 * s] = make_float4(org[0], org[1], org[2], 0.0f);
-            reinterpret_cast<float4 *>(q.rays)[2 * s + 1] = make_float4(dir[0], dir[1], dir[2], 1e12f);
-            q.weights[3 * s] = wgt[0]; q.weights[3 * s + 1] = wgt[1]; q.weights[3 * s + 2] = wgt[2];
-            q.pixels[s] = pix;
-            if (q.ids) q.ids[s] = child_id(id, j);
+            if (s < q.capacity) {
+                float org[3], dir[3], wgt[3];
+                g.make(j, org, dir, wgt);
+                reinterpret_cast<float4 *>(q.rays)[2 * s] = make_float4(org[0], org[1], org[2], 0.0f);
+                reinterpret_cast<float4 *>(q.rays)[2 * s + 1] = make_float4(dir[0], dir[1], dir[2], 1e12f);
+                q.weights[3 * s] = wgt[0]; q.weights[3 * s + 1] = wgt[1]; q.weights[3 * s + 2] = wgt[2];
+                q.pixels[s] = pix;
+                if (q.ids) q.ids[s] = child_id(id, j);
+            }
             s++;
         }
     }

@@ -92,7 +92,8 @@ class FrameDesc(C.Structure):
 class LevelDesc(C.Structure):
     """mr_level_desc (miro_hip.h): one level of traceScene's recursion for mr_trace_level"""
     _fields_ = [("light", Light), ("spp", C.c_uint32), ("flags", C.c_uint32), ("children", C.c_uint32),
-                ("path_kinds", C.c_uint32), ("seed", C.c_uint32), ("bounce", C.c_uint32), ("reserved", C.c_uint32 * 4)]
+                ("path_kinds", C.c_uint32), ("seed", C.c_uint32), ("bounce", C.c_uint32),
+                ("out_capacity_lo", C.c_uint32), ("out_capacity_hi", C.c_uint32), ("reserved", C.c_uint32 * 2)]
 
 
 class Material(C.Structure):
@@ -163,8 +164,8 @@ def load_library(path=None):
     L.mr_tonemap.argtypes = [vp, vp, C.c_uint64, vp, vp]
     L.mr_scene_set_materials.argtypes = [vp, C.POINTER(Material), C.c_uint32, u32p]
     L.mr_shade_accumulate.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, C.POINTER(Light), C.c_uint32, vp, vp]
-    L.mr_gen_secondary_rays.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp, vp]
-    L.mr_gen_path_rays.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp]
+    L.mr_gen_secondary_rays.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp, C.c_uint64, vp]
+    L.mr_gen_path_rays.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, C.c_uint64, vp]
     L.mr_trace_level.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp, vp]
     L.mr_final_gather.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_float, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.mr_photon_map_create.argtypes = [C.c_int32, C.c_uint32, C.POINTER(vp)]
@@ -418,17 +419,21 @@ class Scene:
                                       d_rgb.data_ptr(), _stream_ptr(stream)))
 
     def gen_path_rays(self, d_rays, d_hits, d_weights, d_pixels, d_ids, n, d_out_rays, d_out_weights, d_out_pixels, d_out_ids,
-                      d_count, spp=1, seed=168, bounce=0, kinds=MR_PATH_MIRROR | MR_PATH_REFRACT | MR_PATH_DIFFUSE, stream=None):
-        """mr_gen_path_rays: the PATH_TRACING generators (Ray.h:124-158,235-239): up to 4 children per hit"""
+                      d_count, spp=1, seed=168, bounce=0, kinds=MR_PATH_MIRROR | MR_PATH_REFRACT | MR_PATH_DIFFUSE, stream=None,
+                      out_capacity=None):
+        """mr_gen_path_rays: the PATH_TRACING generators (Ray.h:124-158,235-239): up to 4 children per hit.
+        out_capacity: rays the output tensors hold (default: the shortest of them)"""
         def ptr(t):
             return t.data_ptr() if t is not None else None
+        if out_capacity is None:
+            out_capacity = min(t.shape[0] for t in (d_out_rays, d_out_weights, d_out_pixels, d_out_ids) if t is not None)
         _check(self.L.mr_gen_path_rays(self.h, d_rays.data_ptr(), d_hits.data_ptr(), ptr(d_weights), ptr(d_pixels), ptr(d_ids),
                                        n, spp, seed, bounce, kinds, d_out_rays.data_ptr(), d_out_weights.data_ptr(),
-                                       d_out_pixels.data_ptr(), ptr(d_out_ids), d_count.data_ptr(), _stream_ptr(stream)))
+                                       d_out_pixels.data_ptr(), ptr(d_out_ids), d_count.data_ptr(), out_capacity, _stream_ptr(stream)))
 
     def trace_level(self, d_rays, d_weights, d_pixels, d_ids, n, d_rgb, light_pos, wattage, children=MR_LEVEL_LAST, d_out_rays=None,
                     d_out_weights=None, d_out_pixels=None, d_out_ids=None, d_out_count=None, d_counts=None, spp=1, flags=0,
-                    seed=168, bounce=0, kinds=MR_PATH_MIRROR | MR_PATH_REFRACT, color=(1.0, 1.0, 1.0), stream=None):
+                    seed=168, bounce=0, kinds=MR_PATH_MIRROR | MR_PATH_REFRACT, color=(1.0, 1.0, 1.0), stream=None, out_capacity=None):
         """mr_trace_level: trace -> shadow ray -> trace -> Phong::shade x weight -> pixel, and the next level's queue, in
         one launch (Scene.cpp:270-346)"""
         def ptr(t):
@@ -438,6 +443,10 @@ class Scene:
         ld.light.color[:] = color
         ld.light.wattage = wattage
         ld.spp, ld.flags, ld.children, ld.path_kinds, ld.seed, ld.bounce = spp, flags, children, kinds, seed, bounce
+        if out_capacity is None:
+            outs = [t for t in (d_out_rays, d_out_weights, d_out_pixels, d_out_ids) if t is not None]
+            out_capacity = min(t.shape[0] for t in outs) if outs else 0
+        ld.out_capacity_lo, ld.out_capacity_hi = out_capacity & 0xFFFFFFFF, out_capacity >> 32
         _check(self.L.mr_trace_level(self.h, C.byref(ld), d_rays.data_ptr(), ptr(d_weights), ptr(d_pixels), ptr(d_ids), n,
                                      d_rgb.data_ptr(), ptr(d_out_rays), ptr(d_out_weights), ptr(d_out_pixels), ptr(d_out_ids),
                                      ptr(d_out_count), ptr(d_counts), _stream_ptr(stream)))
@@ -501,12 +510,14 @@ class Scene:
                                           d_shadow_count.data_ptr(), C.byref(lt), spp, d_rgb.data_ptr(), _stream_ptr(stream)))
 
     def gen_secondary_rays(self, d_rays, d_hits, d_weights, d_pixels, n, d_out_rays, d_out_weights, d_out_pixels, d_count,
-                           spp=1, stream=None):
+                           spp=1, stream=None, out_capacity=None):
+        if out_capacity is None:
+            out_capacity = min(t.shape[0] for t in (d_out_rays, d_out_weights, d_out_pixels))
         _check(self.L.mr_gen_secondary_rays(self.h, d_rays.data_ptr(), d_hits.data_ptr(),
                                             d_weights.data_ptr() if d_weights is not None else None,
                                             d_pixels.data_ptr() if d_pixels is not None else None, n, spp,
                                             d_out_rays.data_ptr(), d_out_weights.data_ptr(), d_out_pixels.data_ptr(),
-                                            d_count.data_ptr(), _stream_ptr(stream)))
+                                            d_count.data_ptr(), out_capacity, _stream_ptr(stream)))
 
     def tonemap(self, d_rgb, n_values, d_out, stream=None):
         _check(self.L.mr_tonemap(self.h, d_rgb.data_ptr(), n_values, d_out.data_ptr(), _stream_ptr(stream)))

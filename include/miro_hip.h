@@ -298,10 +298,12 @@ mr_status mr_shade_accumulate(mr_scene *scene, const mr_ray *d_rays, const mr_hi
                               float *d_rgb, void *stream);
 /* Ray::reflect / getReflectionCoefficient / refract (Ray.h:143-243) for every hit on a reflective or refractive
  * material: up to three children per ray (room for 3n), compacted by wave64 ballot + prefix sum, each with its path
- * weight and pixel.  d_count: device uint64 receiving the number of children (zeroed by the call). */
+ * weight and pixel.  d_count: device uint64 receiving the number of children (zeroed by the call).
+ * out_capacity: rays the output arrays have room for.  Children beyond it are counted but not stored: *d_count >
+ * out_capacity afterwards means the queue was too small (3n always suffices) -- nothing is written out of bounds. */
 mr_status mr_gen_secondary_rays(mr_scene *scene, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
                                 const uint32_t *d_pixels, uint64_t n, uint32_t spp, mr_ray *d_out_rays, float *d_out_weights,
-                                uint32_t *d_out_pixels, uint64_t *d_count, void *stream);
+                                uint32_t *d_out_pixels, uint64_t *d_count, uint64_t out_capacity, void *stream);
 
 /* The PATH_TRACING build of those generators (Ray.h:149-158,235-239) plus Ray::random (Ray.h:124-140): every child is
  * drawn from a lobe (alignHemisphereToVector, Utility.h:34-50) around the mirror / refracted direction with
@@ -309,12 +311,13 @@ mr_status mr_gen_secondary_rays(mr_scene *scene, const mr_ray *d_rays, const mr_
  * theta = 2 pi u2.  u1, u2 replace the reference's rand() by the counter-based generator of the eye-ray jitter, keyed by
  * (seed, ray id, bounce, child kind).  kinds selects the children: MR_PATH_MIRROR | MR_PATH_REFRACT (Scene.cpp:302-336)
  * | MR_PATH_DIFFUSE (an extension: traceScene at HEAD never calls Ray::random); up to four children per ray (room for
- * 4n).  d_ids (NULL = ray index) are stable ray ids, d_out_ids (may be NULL) receives the children's. */
+ * 4n).  d_ids (NULL = ray index) are stable ray ids, d_out_ids (may be NULL) receives the children's.  out_capacity as
+ * in mr_gen_secondary_rays (4n always suffices; n when kinds == MR_PATH_DIFFUSE). */
 enum { MR_PATH_MIRROR = 1u, MR_PATH_REFRACT = 2u, MR_PATH_DIFFUSE = 4u };
 mr_status mr_gen_path_rays(mr_scene *scene, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
                            const uint32_t *d_pixels, const uint32_t *d_ids, uint64_t n, uint32_t spp, uint32_t seed,
                            uint32_t bounce, uint32_t kinds, mr_ray *d_out_rays, float *d_out_weights, uint32_t *d_out_pixels,
-                           uint32_t *d_out_ids, uint64_t *d_count, void *stream);
+                           uint32_t *d_out_ids, uint64_t *d_count, uint64_t out_capacity, void *stream);
 
 /* ---- one level of Scene::traceScene's recursion (Scene.cpp:270-346) in ONE launch -------------------------------
  * For every ray of the queue: Scene::trace -> Phong::shade (shadow ray, Scene::trace, the occluder's light scale,
@@ -329,13 +332,16 @@ mr_status mr_gen_path_rays(mr_scene *scene, const mr_ray *d_rays, const mr_hit *
  * generators of mr_gen_secondary_rays, room for 3n) or MR_LEVEL_PATH (those of mr_gen_path_rays with path_kinds, seed
  * and bounce as there, room for 4n).  flags: MR_MATH_PRODUCT, MR_TRACE_INCOHERENT.  d_weights / d_pixels / d_ids /
  * d_out_ids may be NULL as in mr_gen_path_rays.  d_out_count: zeroed by the call, receives the number of children.
+ * out_capacity_lo / _hi (a 64-bit count in two words): rays the output queue has room for, required (> 0) for a level with
+ * children; children beyond it are counted, not stored (*d_out_count > capacity: queue too small, nothing out of bounds).
  * d_counts (may be NULL): [0] += rays traced, [1] += shadow rays traced. */
 enum { MR_LEVEL_LAST = 0u, MR_LEVEL_SPECULAR = 1u, MR_LEVEL_PATH = 2u };
 typedef struct mr_level_desc {
     mr_light light;
     uint32_t spp, flags, children;
     uint32_t path_kinds, seed, bounce;
-    uint32_t reserved[4];
+    uint32_t out_capacity_lo, out_capacity_hi;
+    uint32_t reserved[2];
 } mr_level_desc;
 mr_status mr_trace_level(mr_scene *scene, const mr_level_desc *level, const mr_ray *d_rays, const float *d_weights,
                          const uint32_t *d_pixels, const uint32_t *d_ids, uint64_t n, float *d_rgb, mr_ray *d_out_rays,

@@ -167,3 +167,104 @@ def test_bunny_config3_with_one_diffuse_bounce(oracle, miro):
     h_o = a.trace(cr)
     assert h_o[ko].tobytes() == g_h[kg].tobytes()                             # and their hit records
     assert 0.02 < (h_o["prim"] != oracle.MISS).mean() < 1.0                  # open scene: most bounce rays leave it
+
+
+def _one_glass_triangle(oracle, miro):
+    """a triangle in the plane z = 0 with vertex normals (0, 0, 1), material: rough glass"""
+    verts = np.array([-4, -4, 0, 4, -4, 0, 0, 4, 0], np.float32)
+    a, b = oracle.Scene(), miro.Scene()
+    for s in (a, b):
+        s.add_triangle(verts, [0, 0, 1] * 3)
+    mats = [((0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (0.9, 0.9, 0.9), 50.0, 1.5)]
+    table = np.array([[0, 0, 0, 0, 0, 0, 0.9, 0.9, 0.9, 50.0, 1.5]], np.float32)
+    a.build(4)
+    b.set_materials(mats, np.zeros(1, np.uint32))
+    b.build(4)
+    return a, b, table
+
+
+@pytest.mark.gpu
+def test_incidence_cosine_above_one_gives_the_references_nan(oracle, miro):
+    """ADVICE r2: Ray::getReflectionCoefficient takes acos(dot(-d, n)) (Ray.h:176-188); when that dot product exceeds 1 by
+    rounding -- or, as here, because the caller's direction is a hair longer than 1 -- libm's acosf returns NaN, the Fresnel
+    term Rs is NaN, `Rs > 0.01` is false (no Fresnel reflection child) and the refracted child carries the weight
+    kt * (1 - NaN) = NaN into the pixel.  mm_acosf reproduces that on both sides (no clamp: the reference has none): the
+    children of such a hit are the same on the device and in the oracle, NaN weights included; an in-range neighbour is
+    finite."""
+    import torch
+    a, b, table = _one_glass_triangle(oracle, miro)
+    up = np.float32(1.0) + np.float32(2.0 ** -23)
+    rays = np.zeros(3, miro.RAY_DTYPE)
+    rays["oz"], rays["tmax"] = 1.0, 1e12
+    rays["dz"] = [-up, -1.0, -np.float32(0.8)]
+    rays["dx"][2] = 0.6
+    hits = a.trace(rays)
+    assert (hits["prim"] == 0).all()
+    n = len(rays)
+    d_rays = torch.from_numpy(rays.view(np.float32).reshape(n, 8).copy()).cuda()
+    d_hits = torch.from_numpy(hits.view(np.float32).reshape(n, 4).copy()).cuda()
+    want = a.path_rays(table, np.zeros(1, np.uint32), rays, hits, spp=1, seed=5, bounce=0, kinds=7)
+    got = _device_children(miro, b, d_rays, d_hits, n, 1, 5, 0, 7)
+    assert got[8] == len(want[0])
+    wr, ww, wp, wi = _canon(*want[:4])
+    gr, gw, gp, gi = _canon(*got[:4])
+    assert np.array_equal(wi, gi) and np.array_equal(wp, gp)
+    assert np.array_equal(np.isnan(ww), np.isnan(gw)) and np.array_equal(ww[~np.isnan(ww)], gw[~np.isnan(gw)])
+    kids = {int(p): ww[wp == p] for p in range(3)}
+    assert len(kids[0]) == 1 and np.isnan(kids[0]).all()          # cos > 1: no Fresnel child, a NaN-weighted refraction
+    assert len(kids[1]) >= 1 and np.isfinite(kids[1]).all()       # cos == 1 exactly: acos = 0, everything finite
+    assert len(kids[2]) >= 1 and np.isfinite(kids[2]).all()
+    # the directions of the finite children are the oracle's bits
+    fin = ~np.isnan(ww).any(axis=1)
+    assert wr[fin].tobytes() == gr[fin].tobytes()
+
+
+@pytest.mark.gpu
+def test_child_queues_are_bounded_by_out_capacity(miro):
+    """the generators used to store at whatever slot the atomic counter handed out.  With out_capacity the
+    children beyond the queue's room are counted, not stored: the call reports how many there are and writes nothing out of
+    bounds -- mr_gen_path_rays, mr_gen_secondary_rays and mr_trace_level alike; a capacity of 0 is refused."""
+    import torch
+    from miro_amd import frame as mframe
+    name, W, H, spp = "bunny", 128, 96, 2
+    b = product_scene(miro, name)
+    d = scenes.SCENES[name]
+    n = W * H * spp
+    d_rays = torch.empty((n, 8), dtype=torch.float32, device="cuda")
+    d_hits = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    b.gen_eye_rays(binding.make_camera(d["eye"], d["lookat"], d["up"], d["fov"]), W, H, d_rays, spp=spp, jitter=True)
+    b.trace_device(d_rays, n, d_hits)
+    n_hit = int((d_hits[:, 1].view(torch.int32) != -1).sum().item())
+    cap = 1000
+    assert n_hit > 4 * cap
+    sentinel = 12345.0
+
+    def queues():
+        return (torch.full((n, 8), sentinel, device="cuda"), torch.full((n, 3), sentinel, device="cuda"),
+                torch.full((n,), 77, dtype=torch.int32, device="cuda"), torch.full((n,), 77, dtype=torch.int32, device="cuda"),
+                torch.zeros(1, dtype=torch.int64, device="cuda"))
+
+    def check(q):
+        torch.cuda.synchronize()
+        assert int(q[4].item()) == n_hit                                  # every child counted
+        assert bool((q[0][cap:] == sentinel).all()) and bool((q[1][cap:] == sentinel).all())
+        assert bool((q[2][cap:] == 77).all()) and bool((q[3][cap:] == 77).all())
+        assert bool((q[0][:cap, 7] == 1e12).all())                       # ... and the first `cap` slots hold rays
+
+    q = queues()
+    b.gen_path_rays(d_rays, d_hits, None, None, None, n, q[0], q[1], q[2], q[3], q[4], spp=spp, kinds=binding.MR_PATH_DIFFUSE,
+                    out_capacity=cap)
+    check(q)
+    q = queues()
+    rgb = torch.zeros((W * H, 3), dtype=torch.float32, device="cuda")
+    b.trace_level(d_rays, None, None, None, n, rgb, d["light"], d["wattage"], children=binding.MR_LEVEL_PATH, d_out_rays=q[0],
+                  d_out_weights=q[1], d_out_pixels=q[2], d_out_ids=q[3], d_out_count=q[4], spp=spp, kinds=binding.MR_PATH_DIFFUSE,
+                  out_capacity=cap)
+    check(q)
+    with pytest.raises(miro.MiroError):
+        b.gen_path_rays(d_rays, d_hits, None, None, None, n, q[0], q[1], q[2], q[3], q[4], spp=spp, out_capacity=0)
+    with pytest.raises(miro.MiroError):
+        b.trace_level(d_rays, None, None, None, n, rgb, d["light"], d["wattage"], children=binding.MR_LEVEL_SPECULAR, d_out_rays=q[0],
+                      d_out_weights=q[1], d_out_pixels=q[2], d_out_count=q[4], spp=spp, out_capacity=0)
+    with pytest.raises(miro.MiroError):
+        b.gen_secondary_rays(d_rays, d_hits, None, None, n, q[0], q[1], q[2], q[4], spp=spp, out_capacity=0)

@@ -81,5 +81,12 @@ for f in glob.glob("gpurun_out/r03_children_pmc/trace/**/*kernel_stats.csv", rec
         if i < 8: print(r[:6])
 PY
     ;;
+  children_ab)
+    for v in ${CHILD_VARIANTS:-default _cw4 _cw6 default _cw4 _cw6}; do
+      d=lib$v; [ "$v" = default ] && d=lib
+      echo "== $d" >> $out/children_ab.log
+      MIRO_LIB=$LIB/$d/libmiro_hip.so python tools/bounce_probe.py 2>&1 | grep "bounce generation" >> $out/children_ab.log
+      MIRO_LIB=$LIB/$d/libmiro_hip.so python tools/bounce_probe.py --scene sponza --w 1920 --h 1080 --spp 4 2>&1 | grep "bounce generation" >> $out/children_ab.log
+    done; cat $out/children_ab.log ;;
   *) echo "unknown stage $stage"; exit 2 ;;
 esac
