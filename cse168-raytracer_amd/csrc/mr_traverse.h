@@ -359,21 +359,22 @@ __device__ __forceinline__ void node_decide(float mn0, float mx0, float mn1, flo
 template <bool EXACT, bool STATS, int SLAB, bool SCALAR = false, int OCT = 8>
 __device__ __forceinline__ void node_step(const TraceParams &p, const RayRegs &r, Lane &L, int *s_stack, int tid, Stats &st) {
     float mn0, mx0, mn1, mx1;
-    constexpr bool kSafe = SLAB == 1 || SLAB == 2 || SLAB == 4 || SLAB == 5;
+    constexpr bool kSafe = SLAB == 1 || SLAB == 2 || SLAB == 4 || SLAB == 5 || SLAB == 6;
+    constexpr bool kGuarded = SLAB == 5 || SLAB == 6;
     if (SCALAR) {
         const int cur0 = __builtin_amdgcn_readfirstlane(L.cur);
         if (__all(L.cur == cur0)) {
             const v16f v = load_node_scalar(p.nodes, cur0);
             const float4 q0 = make_float4(v[0], v[1], v[2], v[3]), q1 = make_float4(v[4], v[5], v[6], v[7]);
             const float4 q2 = make_float4(v[8], v[9], v[10], v[11]);
-            if ((SLAB == 4 || SLAB == 5) && __float_as_int(v[14]) != 0) {   // irregular node (wave-uniform): the reference's own divisions
+            if ((SLAB == 4 || kGuarded) && __float_as_int(v[14]) != 0) {   // irregular node (wave-uniform): the reference's own divisions
                 node_slabs<EXACT, STATS, 3>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
                 node_decide<STATS, false>(mn0, mx0, mn1, mx1, __float_as_int(v[12]), __float_as_int(v[13]), r, L, s_stack, st);
                 return;
             }
             float k0 = 0.0f, k1 = 0.0f;
             node_slabs_guarded<EXACT, STATS, SLAB, OCT>(q0, q1, q2, r, L.best_t, mn0, mx0, mn1, mx1, k0, k1);
-            node_decide<STATS, kSafe, SLAB == 5>(mn0, mx0, mn1, mx1, __float_as_int(v[12]), __float_as_int(v[13]), r, L, s_stack, st, k0, k1);
+            node_decide<STATS, kSafe, kGuarded>(mn0, mx0, mn1, mx1, __float_as_int(v[12]), __float_as_int(v[13]), r, L, s_stack, st, k0, k1);
             return;
         }
     }
@@ -381,14 +382,14 @@ __device__ __forceinline__ void node_step(const TraceParams &p, const RayRegs &r
     const float4 *nd = p.nodes + 4 * (size_t)L.cur;
     const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2];
     const int4 q3 = *reinterpret_cast<const int4 *>(nd + 3);
-    if ((SLAB == 4 || SLAB == 5) && q3.z != 0) {
+    if ((SLAB == 4 || kGuarded) && q3.z != 0) {
         node_slabs<EXACT, STATS, 3>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
         node_decide<STATS, false>(mn0, mx0, mn1, mx1, q3.x, q3.y, r, L, s_stack, st);
         return;
     }
     float k0 = 0.0f, k1 = 0.0f;
     node_slabs_guarded<EXACT, STATS, SLAB, OCT>(q0, q1, q2, r, L.best_t, mn0, mx0, mn1, mx1, k0, k1);
-    node_decide<STATS, kSafe, SLAB == 5>(mn0, mx0, mn1, mx1, q3.x, q3.y, r, L, s_stack, st, k0, k1);
+    node_decide<STATS, kSafe, kGuarded>(mn0, mx0, mn1, mx1, q3.x, q3.y, r, L, s_stack, st, k0, k1);
 }
 
 template <bool EXACT, bool STATS, int SLAB, int OCT>
@@ -435,19 +436,29 @@ __device__ __forceinline__ void node_slabs(const float4 q0, const float4 q1, con
 template <bool EXACT, bool STATS, int SLAB, int OCT>
 __device__ __forceinline__ void node_slabs_guarded(const float4 q0, const float4 q1, const float4 q2, const RayRegs &r, float best_t,
                                                    float &mn0, float &mx0, float &mn1, float &mx1, float &k0, float &k1) {
-    if (SLAB != 5) {
+    if (SLAB != 5 && SLAB != 6) {
         node_slabs<EXACT, STATS, SLAB, OCT>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
         return;
     }
     node_slabs<EXACT, STATS, 1, OCT>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
-    // k = minNum(exit, best_t) of both children and the smallest of the five pattern distances, in ONE asm block (separate
+    // k = minNum(exit, best_t) of both children and the smallest of the pattern distances, in ONE asm block (separate
     // asm statements are fenced by hazard no-ops: three s_nop per visit when the two v_min stood alone)
     unsigned near, t0, t1;
-    asm("v_min_f32 %3, %8, %10\n\tv_min_f32 %4, %9, %10\n\t"
-        "v_sad_u32 %0, %5, %3, 0\n\tv_sad_u32 %1, %8, %6, 0\n\tv_sad_u32 %2, %7, %4, 0\n\tv_min3_u32 %0, %0, %1, %2\n\t"
-        "v_sad_u32 %1, %9, %6, 0\n\tv_sad_u32 %2, %5, %7, 0\n\tv_min3_u32 %0, %0, %1, %2"
-        : "=&v"(near), "=&v"(t0), "=&v"(t1), "=&v"(k0), "=&v"(k1)
-        : "v"(mn0), "v"(r.tmin), "v"(mn1), "v"(mx0), "v"(mx1), "v"(best_t));
+    if (SLAB == 6) {
+        // tMin == 0 in every lane of the wave (camera, shadow and bounce rays: all of them): "exit < tMin" is a SIGN test,
+        // and a product and its quotient have the same sign and are zero together -- that comparison needs no guard.
+        // Three pairs are left: entry against min(exit, best) for each child, entry against entry.
+        asm("v_min_f32 %3, %7, %9\n\tv_min_f32 %4, %8, %9\n\t"
+            "v_sad_u32 %0, %5, %3, 0\n\tv_sad_u32 %1, %6, %4, 0\n\tv_sad_u32 %2, %5, %6, 0\n\tv_min3_u32 %0, %0, %1, %2"
+            : "=&v"(near), "=&v"(t0), "=&v"(t1), "=&v"(k0), "=&v"(k1)
+            : "v"(mn0), "v"(mn1), "v"(mx0), "v"(mx1), "v"(best_t));
+    } else {
+        asm("v_min_f32 %3, %8, %10\n\tv_min_f32 %4, %9, %10\n\t"
+            "v_sad_u32 %0, %5, %3, 0\n\tv_sad_u32 %1, %8, %6, 0\n\tv_sad_u32 %2, %7, %4, 0\n\tv_min3_u32 %0, %0, %1, %2\n\t"
+            "v_sad_u32 %1, %9, %6, 0\n\tv_sad_u32 %2, %5, %7, 0\n\tv_min3_u32 %0, %0, %1, %2"
+            : "=&v"(near), "=&v"(t0), "=&v"(t1), "=&v"(k0), "=&v"(k1)
+            : "v"(mn0), "v"(r.tmin), "v"(mn1), "v"(mx0), "v"(mx1), "v"(best_t));
+    }
     if (__any(near <= 16u)) {
         node_slabs<EXACT, STATS, 4, OCT>(q0, q1, q2, r, mn0, mx0, mn1, mx1);
         k0 = vmin2(mx0, best_t); k1 = vmin2(mx1, best_t);
@@ -658,6 +669,7 @@ __device__ __forceinline__ void trace_ray(const TraceParams &p, const RayRegs &r
     constexpr bool kOct = (VAR & 256) != 0;
     constexpr int kExactSlab = (VAR & 512) ? 5 : 4;   // VAR bit 9: guarded products (node_slabs_guarded) instead of the correction steps
     constexpr int kGoodSlab = kMinMax ? kSafeSlab : kExactSlab;
+    constexpr int kOctSlab = kGoodSlab == 5 ? 6 : kGoodSlab;     // the octant loops' guard assumes tMin == 0 (node_slabs_guarded)
     const bool good_wave = kMinMax ? __all(lane_is_nan_free(r) || !live) : ((kStrict && !STATS) ? __all(lane_is_regular(r) || !live) : false);
     bool done_oct = false;
     if (kOct && (kMinMax || (kStrict && !STATS)) && good_wave) {
@@ -665,17 +677,17 @@ __device__ __forceinline__ void trace_ray(const TraceParams &p, const RayRegs &r
         if (m_live) {
             const int oct = octant_of(r);
             const int oct0 = __builtin_amdgcn_readlane(oct, __ffsll((long long)m_live) - 1);
-            if (__all(!live || oct == oct0)) {
+            if (__all(!live || oct == oct0) && (kOctSlab != 6 || __all(!live || r.tmin == 0.0f))) {
                 done_oct = true;
                 switch (oct0) {
-                    case 0: traverse<EXACT, ANY, STATS, kGoodSlab, kWW, kScalar, kObj, 0>(p, r, L, s_stack, tid, st); break;
-                    case 1: traverse<EXACT, ANY, STATS, kGoodSlab, kWW, kScalar, kObj, 1>(p, r, L, s_stack, tid, st); break;
-                    case 2: traverse<EXACT, ANY, STATS, kGoodSlab, kWW, kScalar, kObj, 2>(p, r, L, s_stack, tid, st); break;
-                    case 3: traverse<EXACT, ANY, STATS, kGoodSlab, kWW, kScalar, kObj, 3>(p, r, L, s_stack, tid, st); break;
-                    case 4: traverse<EXACT, ANY, STATS, kGoodSlab, kWW, kScalar, kObj, 4>(p, r, L, s_stack, tid, st); break;
-                    case 5: traverse<EXACT, ANY, STATS, kGoodSlab, kWW, kScalar, kObj, 5>(p, r, L, s_stack, tid, st); break;
-                    case 6: traverse<EXACT, ANY, STATS, kGoodSlab, kWW, kScalar, kObj, 6>(p, r, L, s_stack, tid, st); break;
-                    default: traverse<EXACT, ANY, STATS, kGoodSlab, kWW, kScalar, kObj, 7>(p, r, L, s_stack, tid, st); break;
+                    case 0: traverse<EXACT, ANY, STATS, kOctSlab, kWW, kScalar, kObj, 0>(p, r, L, s_stack, tid, st); break;
+                    case 1: traverse<EXACT, ANY, STATS, kOctSlab, kWW, kScalar, kObj, 1>(p, r, L, s_stack, tid, st); break;
+                    case 2: traverse<EXACT, ANY, STATS, kOctSlab, kWW, kScalar, kObj, 2>(p, r, L, s_stack, tid, st); break;
+                    case 3: traverse<EXACT, ANY, STATS, kOctSlab, kWW, kScalar, kObj, 3>(p, r, L, s_stack, tid, st); break;
+                    case 4: traverse<EXACT, ANY, STATS, kOctSlab, kWW, kScalar, kObj, 4>(p, r, L, s_stack, tid, st); break;
+                    case 5: traverse<EXACT, ANY, STATS, kOctSlab, kWW, kScalar, kObj, 5>(p, r, L, s_stack, tid, st); break;
+                    case 6: traverse<EXACT, ANY, STATS, kOctSlab, kWW, kScalar, kObj, 6>(p, r, L, s_stack, tid, st); break;
+                    default: traverse<EXACT, ANY, STATS, kOctSlab, kWW, kScalar, kObj, 7>(p, r, L, s_stack, tid, st); break;
                 }
             }
         }

@@ -88,5 +88,10 @@ PY
       MIRO_LIB=$LIB/$d/libmiro_hip.so python tools/bounce_probe.py 2>&1 | grep "bounce generation" >> $out/children_ab.log
       MIRO_LIB=$LIB/$d/libmiro_hip.so python tools/bounce_probe.py --scene sponza --w 1920 --h 1080 --spp 4 2>&1 | grep "bounce generation" >> $out/children_ab.log
     done; cat $out/children_ab.log ;;
+  fuzz)
+    # fresh seeds on the round-3 kernels (the hot loop's asm block changed): every mode against the oracle, fused frames and
+    # level kernels against the batched calls
+    MIRO_FUZZ_BASE=${FUZZ_BASE:-90000} MIRO_FUZZ_SEEDS=${FUZZ_SEEDS:-500} python -m pytest tests/test_gpu_fuzz.py -q -m gpu -x > $out/fuzz.log 2>&1
+    tail -n 5 $out/fuzz.log ;;
   *) echo "unknown stage $stage"; exit 2 ;;
 esac
