@@ -93,5 +93,11 @@ PY
     # level kernels against the batched calls
     MIRO_FUZZ_BASE=${FUZZ_BASE:-90000} MIRO_FUZZ_SEEDS=${FUZZ_SEEDS:-500} python -m pytest tests/test_gpu_fuzz.py -q -m gpu -x > $out/fuzz.log 2>&1
     tail -n 5 $out/fuzz.log ;;
+  bench_ab)
+    for v in ${BENCH_VARIANTS:-default _not default _not}; do
+      d=lib$v; [ "$v" = default ] && d=lib
+      echo "== $d" >> $out/bench_ab.log
+      MIRO_LIB=$LIB/$d/libmiro_hip.so python bench.py --no-cpu-baseline --no-pmc --steps 60 $BENCH_ARGS 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.readline()); print(j['value'], j['ms_per_step'], j['config']['workload'])" >> $out/bench_ab.log
+    done; cat $out/bench_ab.log ;;
   *) echo "unknown stage $stage"; exit 2 ;;
 esac
