@@ -99,5 +99,23 @@ PY
       echo "== $d" >> $out/bench_ab.log
       MIRO_LIB=$LIB/$d/libmiro_hip.so python bench.py --no-cpu-baseline --no-pmc --steps 60 $BENCH_ARGS 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.readline()); print(j['value'], j['ms_per_step'], j['config']['workload'])" >> $out/bench_ab.log
     done; cat $out/bench_ab.log ;;
+  profiles)
+    # everything profiles/r03_* is made from: the two bench lines, rocprofv3 summaries of both commands, the other configs
+    python bench.py > $out/r03_bench_line.json 2> $out/bench.err
+    python bench.py --config photon > $out/r03_photon_line.json 2> $out/photon.err
+    bash tools/collect_profiles.sh r03 > $out/collect_r03.log 2>&1
+    bash tools/collect_profiles.sh r03_photon --config photon --steps 2 --warmup 1 --no-cpu-baseline --no-pmc > $out/collect_r03_photon.log 2>&1
+    : > $out/r03_other_configs.jsonl
+    for args in "--scene teapot --width 512 --height 512 --spp 1" "--scene teapot --width 512 --height 512 --spp 1 --mode primary" \
+                "--scene bunny --width 1024 --height 1024 --spp 16" "--spp 1" "--spp 4" "--spp 16" "--width 512 --height 512 --spp 1" \
+                "--scene bunny20 --spp 16" "--scene spiral --width 1024 --height 1024 --spp 16" "--scene cornell --width 256 --height 256 --spp 1" \
+                "--mode primary" "--product"; do
+      python bench.py $args --steps 40 --no-cpu-baseline --no-pmc 2>/dev/null >> $out/r03_other_configs.jsonl
+    done
+    python3 -c "
+import json
+for l in open('$out/r03_other_configs.jsonl'):
+    j = json.loads(l); print('%-60s %10.1f %s  %8.4f ms' % (j['config']['workload'], j['value'], j['unit'], j['ms_per_step']))"
+    cut -c1-300 $out/r03_bench_line.json; cut -c1-300 $out/r03_photon_line.json ;;
   *) echo "unknown stage $stage"; exit 2 ;;
 esac
