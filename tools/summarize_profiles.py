@@ -109,7 +109,30 @@ def main():
             md += ["", "kernel-trace average duration of `%s`: %.4f ms (the bench line's roofline.avg_launch_ms, from HIP events in the "
                    "same run: %s)" % (k, avg_ms, json.dumps(bench_line["roofline"].get("avg_launch_ms")))]
     main_k = [k for k in kernels if k.startswith("trace_kernel<true, false, false")]
-    if not traffic and bench_line and main_k and fetch.get(main_k[0]) and write.get(main_k[0]):
+    irr_k = [k for k in kernels if k.startswith("irradiance_kernel")]
+    if bench_line and irr_k and "estimates_per_step" in bench_line.get("config", {}):
+        # round 3, bench.py --config photon: the step is two launches of irradiance_kernel<false> (the counting build,
+        # irradiance_kernel<true>, runs once per map after the timed region and shows as the slower pair of calls)
+        k = irr_k[0]
+        f = [x for x in fetch.get(k, []) if x > 0]
+        w = [x for x in write.get(k, []) if x > 0]
+        avg = [float(r["AverageNs"]) / 1e6 for r in rows if short(r["Name"]).startswith("irradiance_kernel")]
+        calls = [int(r["Calls"]) for r in rows if short(r["Name"]).startswith("irradiance_kernel")]
+        timed = avg[calls.index(max(calls))] if avg else None
+        md += ["", "## irradiance_kernel", "",
+               "kernel-trace average duration of the timed build (the row with the most calls): %s ms (the bench line's "
+               "roofline.avg_launch_ms, from HIP events in the same run: %s)" % ("%.4f" % timed if timed else "-",
+                                                                               json.dumps(bench_line["roofline"].get("avg_launch_ms")))]
+        if f and w:
+            fb, wb = sum(f) / len(f) * 1024.0 * 2.0, sum(w) / len(w) * 1024.0
+            traffic = {"workload": bench_line["config"]["workload"], "tag": tag, "kernel": k, "fetch_size_kib_raw": sum(f) / len(f),
+                       "write_size_kib_raw": sum(w) / len(w), "fetch_correction": 2.0, "hbm_bytes_per_launch": fb + wb,
+                       "kernel_trace_avg_ms": timed}
+            with open(os.path.join(pdir, "%s_traffic.json" % tag), "w") as out:
+                json.dump(traffic, out, indent=1)
+            md += ["", "HBM traffic per launch (FETCH_SIZE x 2 + WRITE_SIZE, averaged over both builds' dispatches): **%.1f MB** -- the "
+                   "9.6 MB of photon records are read from L2 / MALL, the queries (24 B) and results (12 B) stream." % ((fb + wb) / 1e6)]
+    if not traffic and bench_line and main_k and fetch.get(main_k[0]) and write.get(main_k[0]) and "rays_per_step" in bench_line.get("config", {}):
         k = main_k[0]
         cfg = bench_line["config"]
         # the timed launches are the big ones; the STATS pre-pass uses another template instance
