@@ -246,6 +246,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(STATS ? 
               st_prepass += visits;
           }
       }
+#ifdef MIRO_PHOTON_PREPASS_ONLY      /* timing probe: the reference-order pre-pass alone (results are NOT the estimate) */
+      if (base + (unsigned)lane < nq) { irrad[3 * (base + lane)] = my_radius; if (found_out) found_out[base + lane] = my_mstar; }
+      continue;
+#endif
       const int n_here = nq - base < 64ull ? (int)(nq - base) : 64;
       // The previous query of this wave (the neighbouring pixel) and its final radius: a GUESS for this one's.  If both
       // queries saw the same candidates the k-th nearest of this one would lie within sqrt(prev) + |q - q_prev| (triangle

@@ -113,3 +113,40 @@ def test_bench_gpus_n_refuses_to_measure_fewer_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--rendezvous-only"],
                        capture_output=True, text=True, timeout=300, env=_plain_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert r.returncode != 0 and "must agree" in r.stderr, (r.stdout + r.stderr)[-2000:]
+
+
+@pytest.mark.gpu
+def test_bench_photon_config_prints_one_contract_line():
+    """`bench.py --config photon` (BASELINE config 5) on a small frame and small maps: one JSON line with the driver's fields,
+    the irradiance kernel's `roofline` (live PMC or the committed counters, device work counters, algorithmic bytes) and the
+    oracle-timed `cpu_baseline`."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "photon", "--width", "160", "--height", "90",
+                        "--photons", "20000", "--k", "50", "--steps", "1", "--warmup", "1", "--cpu-queries", "400"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["unit"] == "Mqueries/s" and j["n_gpus"] == 1 and j["rccl_ranks"] == 1 and j["value"] > 0 and j["dtype"] == "f32"
+    assert j["config"]["estimates_per_step"] == 2 * 160 * 90 and j["config"]["k"] == 50      # the atrium is closed: every ray hits
+    rf = j["roofline"]
+    assert rf["bound"] == "valu_issue" and rf["peak"] == 1228.8 and rf["avg_launch_ms"] > 0 and rf["launches_per_step"] == 2
+    w = rf["work_per_launch"]
+    assert w["queries"] == 160 * 90 and w["blocks_of_63_nodes"] > w["queries"] and w["records_searched"] > 50 * w["queries"]
+    assert rf["algorithmic_bytes_per_launch"] >= 32 * (w["records_searched"] + w["records_prepass"])
+    if rf["frac"] is not None:
+        assert 0.0 < rf["frac"] <= 1.0
+    cb = j["cpu_baseline"]
+    assert cb["unit"] == "Mqueries/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port"
+
+
+@pytest.mark.gpu
+def test_bench_primary_only_mode():
+    """`--mode primary` = the -DDISABLE_SHADOWS build: rays counted = primary rays, no shadow ray traced."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scene", "teapot", "--width", "128", "--height", "128", "--spp", "1",
+                        "--mode", "primary", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-pmc"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["metric"] == "Mrays/s (primary)" and j["config"]["rays_per_step"] == 128 * 128
+    assert j["config"]["shadow_query"].startswith("none")

@@ -117,5 +117,20 @@ import json
 for l in open('$out/r03_other_configs.jsonl'):
     j = json.loads(l); print('%-60s %10.1f %s  %8.4f ms' % (j['config']['workload'], j['value'], j['unit'], j['ms_per_step']))"
     cut -c1-300 $out/r03_bench_line.json; cut -c1-300 $out/r03_photon_line.json ;;
+  photon_l2)
+    export TMPDIR=/tmp
+    rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/g1 -- python3 tools/photon_probe.py --reps 1 > $out/g1.log 2>&1
+    rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_REQ_sum TCC_READ_sum --output-format csv -d $out/g2 -- python3 tools/photon_probe.py --reps 1 > $out/g2.log 2>&1
+    python3 - <<'PY'
+import csv, glob
+for g in ("g1", "g2"):
+    acc = {}
+    for f in glob.glob("gpurun_out/r03_photon_l2/%s/**/*counter_collection.csv" % g, recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "irradiance_kernel" in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    print(g, {k: "%.4g" % (sum(v) / len(v)) for k, v in acc.items()}, "dispatches", max([len(v) for v in acc.values()] or [0]))
+PY
+    ;;
   *) echo "unknown stage $stage"; exit 2 ;;
 esac
