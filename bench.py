@@ -345,7 +345,8 @@ def photon_main(a, world, rank, local_dev, dev, red_dev, backend):
                     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
                     json.dump({"workload": workload, "kernel": "irradiance_kernel", "queries_per_launch": nq,
                                "counters_per_launch": pmc, "work_counters": work},
-                              open(os.path.join(ROOT, "gpurun_out", "%s_photon_pmc.json" % ROUND_TAG), "w"), indent=1)
+                              open(os.path.join(ROOT, "gpurun_out", "%s_photon_pmc%s.json" % (ROUND_TAG, "" if (W, H, a.photons, k) == (1920, 1080, 200000, 500)
+                                                                                              else "_%dx%d_%d_k%d" % (W, H, a.photons, k))), "w"), indent=1)
                 except Exception:
                     pass
         if pmc is None:
