@@ -33,7 +33,9 @@ constexpr unsigned kXcdRun = 64, kXcdMinGrid = 16384;
 __device__ __forceinline__ unsigned xcd_block_id() {
     const unsigned G = gridDim.x, b = blockIdx.x;
     if (G < kXcdMinGrid) return b;
-    const unsigned xcd = b & 7u, slot = b >> 3, grp = slot / kXcdRun, k = slot - grp * kXcdRun;
+    const unsigned xcd = b & 7u;
+    const unsigned slot = b >> 3;
+    const unsigned grp = slot / kXcdRun, k = slot - grp * kXcdRun;
     return (grp + 1u) * (8u * kXcdRun) <= G ? grp * (8u * kXcdRun) + xcd * kXcdRun + k : b;      // the ragged tail keeps the plain order
 }
 constexpr float kEps = 1e-4f;        // Miro.h:9

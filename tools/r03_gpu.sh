@@ -132,5 +132,33 @@ for g in ("g1", "g2"):
     print(g, {k: "%.4g" % (sum(v) / len(v)) for k, v in acc.items()}, "dispatches", max([len(v) for v in acc.values()] or [0]))
 PY
     ;;
+  frame_pmc)
+    # where the frame kernel's waiting goes: SMEM / VMEM / LDS instruction cycles, scalar-cache hit rate, instruction fetch
+    export TMPDIR=/tmp
+    LEG="bench.py --pmc-leg --no-cpu-baseline --no-pmc --steps 2 --warmup 1 $FRAME_ARGS"
+    i=0
+    for G in "SQ_INST_CYCLES_SMEM SQ_INSTS_SMEM SQ_INST_CYCLES_SALU SQ_INST_CYCLES_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" \
+             "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE SQC_TC_DATA_READ_REQ SQC_ICACHE_REQ SQC_ICACHE_MISSES SQC_TC_STALL" \
+             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_IFETCH SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS" \
+             "SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_LEVEL_WAVES SQ_INSTS_SMEM_NORM"; do
+      i=$((i+1))
+      rocprofv3 --pmc $G --output-format csv -d $out/g$i -- python3 $LEG > $out/g$i.log 2>&1 || tail -n 3 $out/g$i.log
+    done
+    python3 - <<'PY'
+import csv, glob
+acc = {}
+for f in glob.glob("gpurun_out/r03_frame_pmc/g*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "frame_kernel" in r["Kernel_Name"]:
+            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+m = {k: sum(v) / len(v) for k, v in acc.items()}
+for k in sorted(m): print("%-32s %.5g" % (k, m[k]))
+wc = m.get("SQ_WAVE_CYCLES", 1)
+print("share of wave-cycles: waiting %.3f ; SMEM instruction cycles %.3f ; VMEM_RD %.3f ; SALU %.3f" % (
+    m.get("SQ_WAIT_ANY", 0) / wc, m.get("SQ_INST_CYCLES_SMEM", 0) / wc, m.get("SQ_INST_CYCLES_VMEM_RD", 0) / wc, m.get("SQ_INST_CYCLES_SALU", 0) / wc))
+if m.get("SQC_DCACHE_REQ"): print("scalar cache: hit rate %.3f, misses per request %.3f" % (m["SQC_DCACHE_HITS"] / m["SQC_DCACHE_REQ"], m["SQC_DCACHE_MISSES"] / m["SQC_DCACHE_REQ"]))
+if m.get("SQ_INSTS_SMEM"): print("cycles per SMEM instruction: %.1f" % (m.get("SQ_INST_CYCLES_SMEM", 0) / m["SQ_INSTS_SMEM"]))
+PY
+    ;;
   *) echo "unknown stage $stage"; exit 2 ;;
 esac
