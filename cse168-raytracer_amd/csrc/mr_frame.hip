@@ -169,7 +169,8 @@ mr_status launch_frame_t(const FrameArgs &a, hipStream_t stream) {
         MR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&frame_kernel<VAR, SHADOW, MAT>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     unsigned long long blocks = (a.eye.n + kTraceBlock - 1) / kTraceBlock;
-    if (blocks > (unsigned long long)kTraceGridCap) blocks = kTraceGridCap;
+    const unsigned long long cap = blocks >= kFrameLargeChunks ? (unsigned long long)kFrameGridCapLarge : (unsigned long long)kTraceGridCap;
+    if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((frame_kernel<VAR, SHADOW, MAT>), dim3((unsigned)blocks), dim3(kTraceBlock), lds, stream, a);
     MR_HIP_CHECK(hipGetLastError());
     return MR_OK;

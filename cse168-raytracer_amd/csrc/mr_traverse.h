@@ -23,20 +23,24 @@ constexpr int kBlock = 256;          // 4 waves per workgroup
 #endif
 constexpr int kTraceBlock = MIRO_TRACE_BLOCK;   // threads per workgroup of the trace kernels (their LDS stack is [depth][kTraceBlock])
 constexpr int kTraceGridCap = 32768; // workgroups per trace launch (see launch_trace_t)
+// the fused frame kernel on frames of 2^18 chunks or more (1080p at 64 spp is 518 400): twice the workgroups, and XCD runs of 256
+// chunks instead of 64 -- +1.1 % there, while frames of 4 to 16 samples per pixel lose 1.5-4 % to either (profiles/r03_grid_ab.log)
+constexpr int kFrameGridCapLarge = 65536;
+constexpr unsigned long long kFrameLargeChunks = 1ull << 18;
 
 // Workgroup ids go round-robin to the 8 XCDs, each with its own L2 (not coherent with the others').  In the plain order
 // every XCD traces every eighth 256-ray chunk of the whole image; here an XCD gets runs of kXcdRun consecutive chunks --
 // one region of the image, whole cache lines of the output to itself: +4.9 % on the bench frame, +3 % at 16 and 4 spp
 // (profiles/r02_xcd_runs.log; DESIGN.md section 4.14 for what the counters show).  Only for grids of kXcdMinGrid workgroups or more: a 1-spp frame is 8 100 workgroups,
-// little more than four per resident slot, and there the uneven cost of the regions shows as idle XCDs (-5 %).
-constexpr unsigned kXcdRun = 64, kXcdMinGrid = 16384;
+// little more than four per resident slot, and there the uneven cost of the regions shows as idle XCDs (-5 %).  Round 3: launches that
+// reach kFrameGridCapLarge workgroups (the fused frame kernel at 64 samples per pixel) take runs of kXcdRunLarge chunks.
+constexpr unsigned kXcdRun = 64, kXcdRunLarge = 256, kXcdMinGrid = 16384;
 __device__ __forceinline__ unsigned xcd_block_id() {
     const unsigned G = gridDim.x, b = blockIdx.x;
     if (G < kXcdMinGrid) return b;
-    const unsigned xcd = b & 7u;
-    const unsigned slot = b >> 3;
-    const unsigned grp = slot / kXcdRun, k = slot - grp * kXcdRun;
-    return (grp + 1u) * (8u * kXcdRun) <= G ? grp * (8u * kXcdRun) + xcd * kXcdRun + k : b;      // the ragged tail keeps the plain order
+    const unsigned run = G >= (unsigned)kFrameGridCapLarge ? kXcdRunLarge : kXcdRun;        // only the large-frame launch has that many workgroups
+    const unsigned xcd = b & 7u, slot = b >> 3, grp = slot / run, k = slot - grp * run;
+    return (grp + 1u) * (8u * run) <= G ? grp * (8u * run) + xcd * run + k : b;      // the ragged tail keeps the plain order
 }
 constexpr float kEps = 1e-4f;        // Miro.h:9
 constexpr float kInf = __builtin_huge_valf();
