@@ -25,7 +25,11 @@ constexpr int kTraceBlock = MIRO_TRACE_BLOCK;   // threads per workgroup of the 
 constexpr int kTraceGridCap = 32768; // workgroups per trace launch (see launch_trace_t)
 // the fused frame kernel on frames of 2^18 chunks or more (1080p at 64 spp is 518 400): twice the workgroups, and XCD runs of 256
 // chunks instead of 64 -- +1.1 % there, while frames of 4 to 16 samples per pixel lose 1.5-4 % to either (profiles/r03_grid_ab.log)
-constexpr int kFrameGridCapLarge = 65536;
+#ifndef MIRO_CAP_LARGE
+#define MIRO_CAP_LARGE 65536
+#define MIRO_RUN_LARGE 256
+#endif
+constexpr int kFrameGridCapLarge = MIRO_CAP_LARGE;
 constexpr unsigned long long kFrameLargeChunks = 1ull << 18;
 
 // Workgroup ids go round-robin to the 8 XCDs, each with its own L2 (not coherent with the others').  In the plain order
@@ -34,7 +38,7 @@ constexpr unsigned long long kFrameLargeChunks = 1ull << 18;
 // (profiles/r02_xcd_runs.log; DESIGN.md section 4.14 for what the counters show).  Only for grids of kXcdMinGrid workgroups or more: a 1-spp frame is 8 100 workgroups,
 // little more than four per resident slot, and there the uneven cost of the regions shows as idle XCDs (-5 %).  Round 3: launches that
 // reach kFrameGridCapLarge workgroups (the fused frame kernel at 64 samples per pixel) take runs of kXcdRunLarge chunks.
-constexpr unsigned kXcdRun = 64, kXcdRunLarge = 256, kXcdMinGrid = 16384;
+constexpr unsigned kXcdRun = 64, kXcdRunLarge = MIRO_RUN_LARGE, kXcdMinGrid = 16384;
 __device__ __forceinline__ unsigned xcd_block_id() {
     const unsigned G = gridDim.x, b = blockIdx.x;
     if (G < kXcdMinGrid) return b;
