@@ -332,7 +332,8 @@ def photon_main(a, world, rank, local_dev, dev, red_dev, backend):
             m.count_stats(False)
         rec_search = sum(w["records_searched"] for w in work.values()) / len(maps)
         rec_pre = sum(w["records_prepass"] for w in work.values()) / len(maps)
-        alg_bytes = 32.0 * (rec_search + rec_pre) + 24.0 * nq + 12.0 * nq        # records + query in + irradiance out
+        boxes = sum(w["boxes_measured"] for w in work.values()) / len(maps)
+        alg_bytes = 32.0 * (rec_search + rec_pre) + 64.0 * boxes + 24.0 * nq + 12.0 * nq   # records + child boxes + query in + irradiance out
         workload = "%s %dx%d 1spp hits: %d queries x 2 photon maps of %d, k=%d" % (label, W, H, int(est_per_step / len(maps)), a.photons, k)
         pmc, pmc_source, pmc_note = None, None, None
         if world == 1 and not a.no_pmc:
@@ -360,13 +361,14 @@ def photon_main(a, world, rank, local_dev, dev, red_dev, backend):
         roof = {"kernel": "irradiance_kernel (one launch per photon map and step)", "avg_launch_ms": round(avg_ms, 4),
                 "launches_per_step": len(maps), "pmc_source": pmc_source,
                 "work_per_launch": {"queries": nq, "blocks_of_63_nodes": round(sum(w["blocks"] for w in work.values()) / len(maps)),
+                                    "blocks_expanded": round(sum(w["expansions"] for w in work.values()) / len(maps)), "child_boxes_measured": round(boxes),
                                     "records_searched": round(rec_search), "records_prepass": round(rec_pre),
                                     "tightenings": round(sum(w["tightenings"] for w in work.values()) / len(maps)),
                                     "repeated_searches": round(sum(w["repeated_searches"] for w in work.values()) / len(maps)),
                                     "records_per_query": round((rec_search + rec_pre) / max(nq, 1), 1)},
                 "algorithmic_bytes_per_launch": round(alg_bytes),
-                "algorithmic_definition": "32 B per photon record examined (device counters: cooperative search + reference-order "
-                                          "pre-pass) + 24 B query in + 12 B irradiance out",
+                "algorithmic_definition": "32 B per photon record examined (device counters: block search + reference-order "
+                                          "pre-pass) + 64 B per child-block box pair measured + 24 B query in + 12 B irradiance out",
                 "hbm": {"peak_GBps": HBM_PEAK_GBPS, "nominal_algorithmic_GBps": round(alg_bytes / launch_s / 1e9, 1) if launch_s > 0 else None,
                         "nominal_label": "algorithmic bytes over kernel time; the 9.6 MB of photon records are L2 / MALL resident, so this is not the bound"}}
         if pmc_note:

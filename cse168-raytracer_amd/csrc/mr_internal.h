@@ -193,6 +193,11 @@ struct PhotonMapDev {
     float4 *dir = nullptr;        // incoming direction de-quantised through the reference's tables
     float4 *power = nullptr;      // (r, g, b, -)
     int32_t n = 0, half = 0;      // stored photons; nodes with index < half descend (PhotonMap.cpp:160,357)
+    // Bounding boxes of the tree's BLOCKS (the 63 nodes of six levels below a block root r = 64^L + i, L = 0 .. layers - 1):
+    // four float4 per block id = layer_base[L] + i: (lo, hi) of the block's own 63 photons, (lo, hi) of every photon below
+    // its root.  The cooperative search finds the blocks that touch the search sphere with these instead of walking planes.
+    float4 *boxes = nullptr;
+    int32_t layers = 0, layer_base[4] = {0, 0, 0, 0};
 };
 constexpr int kKnnMaxK = 512;     // nphotons limit of the wave-cooperative k-NN (PHOTON_SAMPLES = 500)
 mr_status launch_irradiance(const PhotonMapDev &pm, const float *d_pos, const float *d_normal, unsigned long long nq,

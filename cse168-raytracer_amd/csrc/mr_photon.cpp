@@ -120,7 +120,7 @@ struct Balancer {
 };
 
 void release(mr_photon_map *m) {
-    (void)hipFree(m->dev.posplane); (void)hipFree(m->dev.dir); (void)hipFree(m->dev.power); (void)hipFree(m->d_stats);
+    (void)hipFree(m->dev.posplane); (void)hipFree(m->dev.dir); (void)hipFree(m->dev.power); (void)hipFree(m->dev.boxes); (void)hipFree(m->d_stats);
     m->dev = PhotonMapDev();
     m->d_stats = nullptr;
     m->on_device = false;
@@ -225,6 +225,48 @@ mr_status mr_photon_map_balance(mr_photon_map *m, uint32_t host_only) {
     MR_HIP_CHECK(hipMemcpy(m->dev.power, p.data(), bytes, hipMemcpyHostToDevice));
     m->dev.n = (int32_t)n;
     m->dev.half = (int32_t)n / 2 - 1;                               // half_stored_photons, PhotonMap.cpp:357
+    // block boxes: bounds of every subtree (bottom-up over the heap), then per block root its own six levels and its subtree
+    {
+        const float inf = INFINITY;
+        std::vector<float> slo(3 * (size_t)(n + 1), inf), shi(3 * (size_t)(n + 1), -inf);
+        for (uint32_t j = n; j >= 1; j--) {
+            const float pj[3] = {a[j].x, a[j].y, a[j].z};
+            for (int c = 0; c < 3; c++) {
+                float lo = pj[c], hi = pj[c];
+                for (uint32_t ch = 2 * j; ch <= 2 * j + 1 && ch <= n; ch++) {
+                    lo = std::min(lo, slo[3 * (size_t)ch + c]);
+                    hi = std::max(hi, shi[3 * (size_t)ch + c]);
+                }
+                slo[3 * (size_t)j + c] = lo; shi[3 * (size_t)j + c] = hi;
+            }
+        }
+        int layers = 0;
+        size_t total = 0;
+        for (uint64_t first = 1; first <= n && layers < 4; first <<= 6) { m->dev.layer_base[layers++] = (int32_t)total; total += (size_t)first; }
+        m->dev.layers = layers;
+        std::vector<float4> boxes(4 * std::max<size_t>(total, 1), make_float4(inf, inf, inf, 0.f));
+        for (size_t i = 0; i < boxes.size(); i += 2) boxes[i + 1] = make_float4(-inf, -inf, -inf, 0.f);
+        uint64_t first = 1;
+        for (int L = 0; L < layers; L++, first <<= 6) {
+            for (uint64_t r = first; r < 2 * first && r <= n; r++) {
+                float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+                for (int l = 0; l < 6; l++)
+                    for (uint64_t o = 0; o < (1ull << l); o++) {
+                        const uint64_t j = (r << l) + o;
+                        if (j > n) break;
+                        const float pj[3] = {a[j].x, a[j].y, a[j].z};
+                        for (int c = 0; c < 3; c++) { lo[c] = std::min(lo[c], pj[c]); hi[c] = std::max(hi[c], pj[c]); }
+                    }
+                float4 *b = &boxes[4 * ((size_t)m->dev.layer_base[L] + (size_t)(r - first))];
+                b[0] = make_float4(lo[0], lo[1], lo[2], 0.f);
+                b[1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+                b[2] = make_float4(slo[3 * r], slo[3 * r + 1], slo[3 * r + 2], 0.f);
+                b[3] = make_float4(shi[3 * r], shi[3 * r + 1], shi[3 * r + 2], 0.f);
+            }
+        }
+        MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->dev.boxes), boxes.size() * sizeof(float4)));
+        MR_HIP_CHECK(hipMemcpy(m->dev.boxes, boxes.data(), boxes.size() * sizeof(float4), hipMemcpyHostToDevice));
+    }
     m->on_device = true;
     return MR_OK;
 }

@@ -1,18 +1,21 @@
 // mr_photon.hip -- Photon_map::irradiance_estimate / locate_photons (PhotonMap.cpp:81-243) on gfx950:
 // one wave64 per query, the k-nearest candidate set in LDS.
 //
-// The reference walks the implicit kd-tree one node at a time with a 500-entry max-heap per query.  Here a wave
-// takes a *block* of the heap-ordered tree per step: the 63 nodes of six consecutive levels below a block root b
-// are b*2^l + o (contiguous per level, so the loads coalesce), one node per lane.  Every lane decides whether its
-// node is reachable under the reference's pruning rule (near side always, far side only if the splitting plane is
-// closer than the current search radius) by pulling its ancestors' decisions from their lanes (__shfl), tests its
-// photon (distance, facing), and accepted photons are appended to the LDS candidate buffer by ballot + prefix sum.
-// Level-5 lanes push their reachable children as new block roots (far children first, so near ones pop first).
-// When the buffer is nearly full the wave selects the k smallest distances (4-pass radix select on the float bits,
-// LDS histogram) and the k-th becomes the new radius -- the same radius the reference's heap would hold after
-// seeing those photons, applied lazily, so a superset of nodes is visited and the same k photons survive.
+// The reference walks the implicit kd-tree one node at a time with a 500-entry max-heap per query.  What it returns is a SET --
+// the k nearest facing photons inside the radius (minus one, see below) -- and a set can be found in any order.  Here a wave
+// works on BLOCKS of the heap-ordered tree: the 63 nodes of six consecutive levels below a block root b are b*2^l + o
+// (contiguous per level, so the loads coalesce), one node per lane, and every block carries two bounding boxes made at
+// balance time (of its own 63 photons, and of everything below its root).  A search is two interleaved phases: EXPAND hands
+// each lane one of a pending block's 64 child blocks and measures the query's distance to the child's boxes -- children
+// whose own box reaches into the radius are listed, children whose subtree box does are expanded in turn --, EXAMINE tests
+// the 63 photons of a listed block (distance, facing) and appends accepted ones to the LDS candidate buffer by ballot +
+// prefix sum, four listed blocks per step with all their loads in flight together.  When the buffer is nearly full the wave
+// selects the k smallest distances (4-pass radix select on the float bits, LDS histogram) and the k-th becomes the new
+// radius.  (Rounds 1-2 walked the kd-tree's planes block by block in the reference's order, with the lanes of a block
+// pulling their ancestors' decisions through shuffles: a serial chain of ~2 300 cycles per block and 93 blocks per query
+// where the boxes need 61 independent ones; 41.5 -> 24 ms per 2.07 M queries, results identical.)
 //
-// Kept from the reference: nodes with index >= stored/2-1 do not descend; the normalising radius stays
+// Kept from the reference: nodes with index >= stored/2-1 do not descend (the photons below them are never found); the normalising radius stays
 // max_dist^2 unless more than k candidates were seen; strict comparisons; and the FIRST-OVERFLOW REPLACEMENT
 // (PhotonMap.cpp:195-240): when candidate k+1 arrives the reference heapifies the k it holds and replaces the heap
 // root -- the farthest of the first k, m* -- by the newcomer even when the newcomer is farther still, and only from
@@ -39,30 +42,32 @@ constexpr int kTighten = 640;      // compress (tighten the radius) once this ma
 #endif
 constexpr float kGuessMargin = MIRO_PHOTON_GUESS_MARGIN;   // on the guessed squared radius (see the kernel)
 
-// A wave's LDS (dynamic, sized at launch): the candidate buffer, the stack of pending block roots -- an expanded block
-// leaves at most 64 roots of the next layer of blocks pending and the newest are popped first, so 64 x (layers - 1)
-// entries: 128 for up to 2^18 photons instead of a fixed 256 -- and the radix-select histogram, which shares its words
-// with the child slots of the push phase (the two are never live together).  7 680 bytes per wave for a 200 000-photon
-// map: five waves per SIMD where the fixed 9 216-byte layout allowed four.
+// A wave's LDS (dynamic, sized at launch): the candidate buffer, the radix-select histogram, the stack of blocks whose
+// children are still to be measured (only blocks with blocks below them wait there: 64 x (layers - 2) entries, at least 64)
+// and the list of blocks to examine.  7 936 bytes per wave for a 200 000-photon map: five waves per SIMD (round 2's fixed
+// 9 216-byte layout allowed four; the fifth is worth 21 %).
 struct WaveLds {
     float *d2;               // [kCap]
     int *idx;                // [kCap]
     unsigned *hist;          // [256]
-    int *slot;               // [64]   children of one block, indexed by visiting-order key   (= hist)
-    float *slot_lb;          // [64]                                                           (= hist + 64)
-    int *stack;              // [stack_cap] pending block roots
-    float *lb;               // [stack_cap] per pending block: squared distance of the farthest plane crossed on the far side
+    int *stack;              // [stack_cap] pending block roots whose children are still to be tested
+    int *list;               // [kList] blocks to examine
+    float *lb;               // [kList] squared distance from the query to each listed block's own box
 };
-__host__ __device__ inline int wave_lds_words(int stack_cap) { return 2 * kCap + 256 + 2 * stack_cap; }
+#ifndef MIRO_PHOTON_EXAMINE
+#define MIRO_PHOTON_EXAMINE 4
+#endif
+constexpr int kExamine = MIRO_PHOTON_EXAMINE;   // listed blocks examined per step (their loads are in flight together)
+constexpr int kList = 128;         // an expansion adds up to 64 entries and runs only while at most kList - 64 are waiting
+__host__ __device__ inline int wave_lds_words(int stack_cap) { return 2 * kCap + 256 + stack_cap + 2 * kList; }
 __device__ __forceinline__ WaveLds wave_lds(int *base, int stack_cap) {
     WaveLds w;
     w.d2 = reinterpret_cast<float *>(base);
     w.idx = base + kCap;
     w.hist = reinterpret_cast<unsigned *>(base + 2 * kCap);
-    w.slot = base + 2 * kCap;
-    w.slot_lb = reinterpret_cast<float *>(base + 2 * kCap + 64);
     w.stack = base + 2 * kCap + 256;
-    w.lb = reinterpret_cast<float *>(base + 2 * kCap + 256 + stack_cap);
+    w.list = base + 2 * kCap + 256 + stack_cap;
+    w.lb = reinterpret_cast<float *>(base + 2 * kCap + 256 + stack_cap + kList);
     return w;
 }
 
@@ -205,9 +210,9 @@ __device__ __forceinline__ int first_overflow(const PhotonMapDev &pm, float qx, 
     }
 }
 
-// STATS: work counters of the launch, added to stats[0..5] (mr_photon_map_get_stats): queries answered, blocks expanded,
-// photon records examined by the cooperative search (32 bytes each: position + direction), radius tightenings,
-// photon records examined by the reference-order pre-pass, searches repeated with the safe radius.
+// STATS: work counters of the launch, added to stats[] (mr_photon_map_get_stats, miro_hip.h): queries answered, blocks examined,
+// photon records examined by the search (32 bytes each: position + direction), radius tightenings, photon records examined by
+// the reference-order pre-pass, searches repeated with the safe radius, child boxes measured, candidates, blocks expanded.
 // Five waves per SIMD (96 registers) is what 7 680 bytes of LDS per wave allow; the fifth wave is worth 21 % (50.3 -> 41.5 ms),
 // so the register allocation is held to it.
 template <bool STATS>
@@ -291,102 +296,100 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(STATS ? 
       search_again:
         count = 0;
         evicted = false;
-        int sp = 0;
-        if (pm.n >= 1) { if (lane == 0) { w.stack[0] = 1; w.lb[0] = 0.0f; } sp = 1; }
-
-        // LDS words written by one lane and read by another lane of the same wave: the hardware keeps a wave's LDS
-        // operations in order, the compiler is kept from moving them across each hand-off by lds_handoff()
+        // Two phases share one loop.  EXPAND: a pending block root r (LDS stack, newest first) hands each lane one of its 64
+        // child blocks: the lane reads that child's two boxes and computes the squared distance from the query to the box of
+        // the child's own 63 photons and to the box of everything below it -- per axis e = lo - q, hi - q or 0, summed in the
+        // order the photon test sums, so that (floating-point operations being monotone) no photon inside a box computes
+        // nearer than its box.  Children whose own box reaches into the radius go on the LIST, children whose subtree box does
+        // and which have blocks below them go on the stack.  EXAMINE: a listed block's 63 photons are tested, one per lane,
+        // and accepted ones appended to the candidate buffer.  Which blocks are examined no longer depends on one another:
+        // the result is the set of facing photons inside the radius whichever way they are found.
+        int sp = 0, nlist = 0;
+        if (pm.n >= 1) {
+            if (lane == 0) { w.stack[0] = 1; w.list[0] = 1; w.lb[0] = 0.0f; }
+            sp = pm.layers > 1 ? 1 : 0;
+            nlist = 1;
+        }
         lds_handoff();
-        while (sp > 0) {
-            sp--;
-            const int b = w.stack[sp];                        // same address in every lane: LDS broadcast
-            const float lb_block = w.lb[sp];
-            if (lb_block >= r2) continue;                     // the plane that led here is no longer inside the radius
-            const int jj = (b << lv) + off_in_level;          // < 2^24 (checked at launch)
-            const bool valid = node_lane && jj <= pm.n;
-            const int j = valid ? jj : 0;
-            float4 A = make_float4(0.f, 0.f, 0.f, 0.f), D = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid) { A = pm.posplane[j]; D = pm.dir[j]; }
-            if (STATS) { st_blocks++; st_records += (unsigned)__popcll(__ballot(valid)); if (b < 64) st_top++; else if (b < 4096) st_mid++; }
-            const int plane = __float_as_int(A.w);
-            const float pc = plane == 0 ? A.x : (plane == 1 ? A.y : A.z);
-            const float qc = plane == 0 ? qx : (plane == 1 ? qy : qz);
-            const float d1 = qc - pc;                         // :161
-            const bool desc = valid && j < pm.half;           // :160
-            // Reachability inside the block.  A lane's node is reached iff every step from the block root down to it is
-            // allowed by the reference's rule (:163-172): the near side always, the far side only if the splitting
-            // plane is inside the radius.  Each lane walks its own ancestor chain: the ancestors' plane distances come
-            // from their lanes through independent __shfl's (no level-by-level dependency), their "descends" flag
-            // from the index alone.  `path` collects the far-side steps (most significant = nearest the block root),
-            // which is the order the reference's near-first recursion visits subtrees in; `lb` is the largest squared
-            // plane distance crossed on the far side (a lower bound of the distance to anything below).
-            // every ancestor inside the block must descend (index < half, :160); indices grow downwards, so the
-            // parent's test covers them all
-            bool reach = valid && (lv == 0 || (j >> 1) < pm.half);
-            int path = 0;
-            float lb = lb_block;
-            float a_d1[5];
-#pragma unroll
-            for (int s = 1; s <= 5; s++) {                                          // five ds_bpermute in flight together
-                const int anc_lane = ((lane + 1) >> s) - 1;                         // -1 (-> lane 63, unused) above the root
-                a_d1[s - 1] = __shfl(d1, anc_lane & 63, 64);
-            }
-#pragma unroll
-            for (int s = 1; s <= 5; s++) {                                          // branch-free: `s <= lv` is a lane constant
-                // the low lv bits of the index are the lane's offset in its level: which side it is on is a lane constant
-                const bool is_right = ((off_in_level >> (s - 1)) & 1) != 0, near_right = a_d1[s - 1] > 0.0f;
-                const bool far_step = (s <= lv) && (is_right != near_right);
-                const float pd2 = a_d1[s - 1] * a_d1[s - 1];
-                reach = reach && (!far_step || pd2 < r2);
-                path |= (far_step ? 1 : 0) << (s - 1);
-                lb = (far_step && pd2 > lb) ? pd2 : lb;
-            }
-            // the photon itself (:177-186)
-            float dd = A.x - qx;
-            float d2 = dd * dd;
-            dd = A.y - qy; d2 += dd * dd;
-            dd = A.z - qz; d2 += dd * dd;
-            const float facing = (D.x * nx + D.y * ny) + D.z * nz;
-            const bool cand = reach && d2 < r2 && facing < 0.0f && j != mstar;      // m* never takes part (see the header)
-            const unsigned long long mc = __ballot(cand);
-            if (cand) {
-                const int pos = count + __popcll(mc & ((1ull << lane) - 1ull));
-                w.d2[pos] = d2; w.idx[pos] = j;
-            }
-            count += __popcll(mc);
-            if (STATS) { st_reached += (unsigned)__popcll(__ballot(reach)); st_cands += (unsigned)__popcll(mc); }
-            // children of the level-5 nodes become block roots, pushed so that they pop in the reference's order:
-            // key = far-step bits of the whole path (6 bits, unique per child); slot[key] is filled by its owner,
-            // then lane `key` moves it to the stack behind all larger keys.  (Computing path / lb only in blocks that push was measured:
-            // 43.5 vs 41.5 ms -- the shuffled distances stay live longer.)  A block whose level-5 nodes do not descend
-            // (b * 32 >= half: the bottom layer of blocks, most of those a query touches) has nothing to push.
-            if ((b << 5) < pm.half) {
-                lds_handoff();                                // candidate append above / slot reuse below
-                w.slot[lane] = 0;
-                lds_handoff();
-                const bool can_push = valid && lv == 5 && reach && desc;
-                const int near_child = d1 > 0.0f ? 2 * j + 1 : 2 * j;
-                const int far_child = near_child ^ 1;
-                const float dsq = d1 * d1;
-                if (can_push && near_child <= pm.n) { w.slot[path << 1] = near_child; w.slot_lb[path << 1] = lb; }
-                if (can_push && far_child <= pm.n && dsq < r2) { w.slot[(path << 1) | 1] = far_child; w.slot_lb[(path << 1) | 1] = fmaxf(lb, dsq); }
-                lds_handoff();                                // slot[] filled by the level-5 lanes, read by lane `key`
-                const int child = w.slot[lane];
-                const float child_lb = w.slot_lb[lane];
-                const unsigned long long mp = __ballot(child != 0);
-                if (child != 0) {
-                    const unsigned long long higher = lane == 63 ? 0ull : (mp >> (lane + 1));
-                    const int pos = sp + __popcll(higher);
-                    w.stack[pos] = child; w.lb[pos] = child_lb;
+        while (sp > 0 || nlist > 0) {
+            if (sp > 0 && nlist <= kList - 64) {
+                // ---- expand
+                sp--;
+                const int r = w.stack[sp];                                      // broadcast
+                const int L = (31 - __clz(r)) / 6;                              // r's layer; its children are layer L + 1
+                const int child = (r << 6) + lane;
+                const bool valid = child <= pm.n;
+                float d_own = 0.0f, d_sub = 0.0f;
+                if (valid) {
+                    const float4 *bx = pm.boxes + 4 * (size_t)(pm.layer_base[L + 1] + (child - (1 << (6 * (L + 1)))));
+                    const float4 olo = bx[0], ohi = bx[1], slo = bx[2], shi = bx[3];
+                    float e = qx < olo.x ? olo.x - qx : (qx > ohi.x ? ohi.x - qx : 0.0f);
+                    d_own = e * e;
+                    e = qy < olo.y ? olo.y - qy : (qy > ohi.y ? ohi.y - qy : 0.0f); d_own += e * e;
+                    e = qz < olo.z ? olo.z - qz : (qz > ohi.z ? ohi.z - qz : 0.0f); d_own += e * e;
+                    e = qx < slo.x ? slo.x - qx : (qx > shi.x ? shi.x - qx : 0.0f);
+                    d_sub = e * e;
+                    e = qy < slo.y ? slo.y - qy : (qy > shi.y ? shi.y - qy : 0.0f); d_sub += e * e;
+                    e = qz < slo.z ? slo.z - qz : (qz > shi.z ? shi.z - qz : 0.0f); d_sub += e * e;
                 }
-                sp += __popcll(mp);
-                lds_handoff();                                // stack[] / lb[] entries are popped by every lane next round
+                if (STATS) { st_top++; st_reached += (unsigned)__popcll(__ballot(valid)); }
+                const bool look = valid && d_own < r2;
+                const bool down = valid && d_sub < r2 && ((long long)child << 6) <= (long long)pm.n;
+                const unsigned long long ml = __ballot(look), md = __ballot(down), lt = (1ull << lane) - 1ull;
+                if (look) { const int pos = nlist + __popcll(ml & lt); w.list[pos] = child; w.lb[pos] = d_own; }
+                if (down) w.stack[sp + __popcll(md & lt)] = child;
+                nlist += __popcll(ml);
+                sp += __popcll(md);
+                lds_handoff();                                                  // list / stack entries are read by every lane
+                continue;
             }
-            if (count > kTighten && count > k) {              // keep the k nearest so far; the k-th is the new radius
-                lds_handoff();                                // the candidates appended above are read by other lanes
-                r2 = compress(w, count, k, lane);
-                evicted = true;
-                if (STATS) st_tighten++;
+            // ---- examine: up to kExamine listed blocks per step -- all their records are requested before any is tested
+            // (the steps no longer depend on one another, only on the candidate count and the radius)
+            int jb[kExamine];
+            bool go[kExamine], vb[kExamine];
+            float4 Ab[kExamine], Db[kExamine];
+#pragma unroll
+            for (int u = 0; u < kExamine; u++) {
+                go[u] = false; jb[u] = 0;
+                if (nlist > 0) {                                                // wave-uniform
+                    nlist--;
+                    const int bu = w.list[nlist];                               // broadcast
+                    go[u] = w.lb[nlist] < r2;                                   // else: the radius has shrunk below this block meanwhile
+                    jb[u] = (bu << lv) + off_in_level;                          // < 2^24 (checked at launch)
+                }
+                vb[u] = go[u] && node_lane && jb[u] <= pm.n;
+                Ab[u] = make_float4(0.f, 0.f, 0.f, 0.f); Db[u] = Ab[u];
+                if (vb[u]) { Ab[u] = pm.posplane[jb[u]]; Db[u] = pm.dir[jb[u]]; }
+            }
+#pragma unroll
+            for (int u = 0; u < kExamine; u++) {
+                if (!go[u]) continue;                                           // wave-uniform
+                const bool valid = vb[u];
+                const int j = jb[u];
+                const float4 A = Ab[u], D = Db[u];
+                if (STATS) { st_blocks++; st_records += (unsigned)__popcll(__ballot(valid)); }
+                // the photon itself (:177-186)
+                float dd = A.x - qx;
+                float d2 = dd * dd;
+                dd = A.y - qy; d2 += dd * dd;
+                dd = A.z - qz; d2 += dd * dd;
+                const float facing = (D.x * nx + D.y * ny) + D.z * nz;
+                // the reference never descends below a node of index >= half_stored_photons (:160): the two or three photons
+                // whose parent is such a node are never found by it -- nor here; m* never takes part either (see the header)
+                const bool cand = valid && d2 < r2 && facing < 0.0f && j != mstar && (j == 1 || (j >> 1) < pm.half);
+                const unsigned long long mc = __ballot(cand);
+                if (cand) {
+                    const int pos = count + __popcll(mc & ((1ull << lane) - 1ull));
+                    w.d2[pos] = d2; w.idx[pos] = j;
+                }
+                count += __popcll(mc);
+                if (STATS) st_cands += (unsigned)__popcll(mc);
+                if (count > kTighten && count > k) {          // keep the k nearest so far; the k-th is the new radius
+                    lds_handoff();                            // the candidates appended above are read by other lanes
+                    r2 = compress(w, count, k, lane);
+                    evicted = true;
+                    if (STATS) st_tighten++;
+                }
             }
         }
         if (guessed && count < k) {                           // the guessed radius does not hold the k nearest: the safe one
@@ -443,7 +446,7 @@ mr_status launch_irradiance(const PhotonMapDev &pm, const float *d_pos, const fl
     // layers of 6-level blocks that hold nodes; an expanded block leaves at most 64 roots of the next layer pending
     int layers = 1;
     while (layers < 4 && (1ll << (6 * layers)) <= (long long)pm.n) layers++;
-    const int stack_cap = layers > 1 ? 64 * (layers - 1) : 64;
+    const int stack_cap = layers > 2 ? 64 * (layers - 2) : 64;      // only blocks that have blocks below them wait on the stack
     const size_t lds = (size_t)kWaves * wave_lds_words(stack_cap) * sizeof(int);
     unsigned long long blocks = (nq + kWaves - 1) / kWaves;
     if (blocks > 256ull * 20ull) blocks = 256ull * 20ull;

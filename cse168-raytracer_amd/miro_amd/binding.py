@@ -573,8 +573,8 @@ class PhotonMap:
                                              d_irrad.data_ptr(), d_found.data_ptr() if d_found is not None else None,
                                              d_r2.data_ptr() if d_r2 is not None else None, _stream_ptr(stream)))
 
-    STAT_NAMES = ("queries", "blocks", "records_searched", "tightenings", "records_prepass", "repeated_searches", "reached",
-                  "candidates", "blocks_top", "blocks_mid", "unguessed", "unused")
+    STAT_NAMES = ("queries", "blocks", "records_searched", "tightenings", "records_prepass", "repeated_searches", "boxes_measured",
+                  "candidates", "expansions", "unused9", "unguessed", "unused11")
 
     def count_stats(self, enable=True):
         """mr_photon_map_count_stats: the estimates on this map run the counting build of the kernel while enabled."""

@@ -372,12 +372,12 @@ mr_status mr_irradiance_estimate(mr_photon_map *map, const float *d_pos, const f
                                  void *stream);
 /* Work counters of the estimates on this map, like MR_COUNT_STATS for the traversal (the reference has no counterpart:
  * Stats.h counts nothing in PhotonMap.cpp).  While enabled, every mr_irradiance_estimate / mr_final_gather on the map runs
- * the counting build of the kernel and adds to: [0] queries answered, [1] blocks of 63 kd-tree nodes expanded, [2] photon
+ * the counting build of the kernel and adds to: [0] queries answered, [1] blocks of 63 kd-tree nodes examined, [2] photon
  * records (position + direction, 32 bytes) examined by the search, [3] radius tightenings (k-th-nearest selections),
  * [4] photon records examined by the reference-order pre-pass that finds the first overflow's victim
- * (PhotonMap.cpp:195-240), [5] searches repeated because a guessed radius did not hold the k nearest, [6] nodes the
- * reference's pruning rule reaches inside the expanded blocks, [7] candidates buffered, [8] / [9] expanded blocks among the top
- * 6 / the next 6 tree levels, [10] queries searched from the pre-pass's safe radius (no guess available), [11] unused. */
+ * (PhotonMap.cpp:195-240), [5] searches repeated because a guessed radius did not hold the k nearest, [6] child-block boxes
+ * measured (64 bytes each), [7] candidates buffered, [8] blocks expanded (64 child boxes each), [10] queries searched from
+ * the pre-pass's safe radius (no guess available); [9], [11] unused. */
 mr_status mr_photon_map_count_stats(mr_photon_map *map, int32_t enable);
 mr_status mr_photon_map_get_stats(mr_photon_map *map, uint64_t counters[12], int32_t reset);
 

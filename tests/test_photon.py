@@ -173,3 +173,34 @@ def test_final_gather_frame_matches_oracle(oracle, miro, name, W, H, rows, spp, 
     # pixels whose samples all missed receive nothing
     all_miss = ~hit.reshape((y1 - y0) * W, spp).any(axis=1)
     assert (all_miss.any() or name == "sponza") and (added[all_miss] == 0).all()      # the atrium is closed: every ray hits
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [200000, 4097, 130])
+def test_photons_below_the_last_descending_node_are_never_found(oracle, miro, n):
+    """`locate_photons` descends only below nodes of index < half_stored_photons = n/2 - 1 (PhotonMap.cpp:160,357): the children
+    of nodes n/2 - 1 and n/2 -- the last two or three photons of the heap -- are unreachable, however near the query is.  The
+    block search finds photons by their boxes, not by walking down to them, and must leave exactly those out: queries placed
+    ON the last photons of the heap, facing them, give the oracle's `found` / radius, and a radius of 0 (the photon itself
+    as nearest neighbour) only where the reference can reach it."""
+    import torch
+    a, b, _ = make_maps(oracle, miro, n, scene="sponza", host_only=False)
+    pos, plane, tp, power = a.export()                      # heap order: pos[i - 1] is node i
+    last = np.arange(max(1, n - 8), n + 1)                  # the heap's last nodes, 1-based
+    qpos = pos[last - 1].astype(np.float32)
+    # face every photon: the normal opposes the photon's de-quantised direction
+    th, ph = tp[last - 1, 0].astype(np.float64) / 256.0 * np.pi, tp[last - 1, 1].astype(np.float64) / 256.0 * 2 * np.pi
+    qn = -np.stack([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)], axis=1).astype(np.float32)
+    for k in (1, 5):
+        want, found, r2 = a.irradiance_estimate(qpos, qn, max_dist=1e10, nphotons=k)
+        out = torch.empty((len(qpos), 3), dtype=torch.float32, device="cuda")
+        df = torch.empty(len(qpos), dtype=torch.int32, device="cuda")
+        dr = torch.empty(len(qpos), dtype=torch.float32, device="cuda")
+        b.irradiance_estimate(torch.from_numpy(qpos).cuda(), torch.from_numpy(qn).cuda(), len(qpos), out, max_dist=1e10, nphotons=k,
+                              d_found=df, d_r2=dr)
+        torch.cuda.synchronize()
+        assert np.array_equal(df.cpu().numpy(), found)
+        assert np.array_equal(dr.cpu().numpy().view(np.uint32), r2.view(np.uint32))
+    half = n // 2 - 1
+    unreachable = (last // 2) >= half
+    assert unreachable.any() and not unreachable.all()

@@ -17,6 +17,8 @@ ap.add_argument("--k", type=int, default=500)
 ap.add_argument("--w", type=int, default=1920)
 ap.add_argument("--h", type=int, default=1080)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--dump", default="", help="save found / r2 of every query to this .npz")
+ap.add_argument("--random-queries", type=int, default=0, help="scattered query points on the surfaces instead of the frame's hits")
 a = ap.parse_args()
 sc = miro_amd.Scene(0); scenes.populate(sc, a.scene); sc.build(4)
 v, _, vi, _ = sc.arrays()
@@ -30,10 +32,14 @@ sc.hit_attrs(fr.d_hits, n, P, N)
 N = N / N.norm(dim=1, keepdim=True)
 hit = fr.d_hits.view(torch.int32)[:, 1] != -1
 P, N = P[hit].contiguous(), N[hit].contiguous()
+if a.random_queries:
+    _, qpos, qdir = scenes.synthetic_photons(v, vi, a.random_queries, seed=99)
+    P, N = torch.from_numpy(qpos).cuda(), torch.from_numpy(-qdir).cuda()
 nq = P.shape[0]
 out = torch.empty((nq, 3), device="cuda"); fnd = torch.empty(nq, dtype=torch.int32, device="cuda")
+r2o = torch.empty(nq, dtype=torch.float32, device="cuda")
 st = torch.cuda.current_stream()
-pm.irradiance_estimate(P, N, nq, out, nphotons=a.k, d_found=fnd, stream=st)
+pm.irradiance_estimate(P, N, nq, out, nphotons=a.k, d_found=fnd, d_r2=r2o, stream=st)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(st)
 for _ in range(a.reps):
@@ -43,9 +49,12 @@ ms = e0.elapsed_time(e1) / a.reps
 print("%d queries, k=%d: %.2f ms  %.2f Mqueries/s  (found min %d max %d, mean irradiance %.4g)" %
       (nq, a.k, ms, nq / ms / 1e3, int(fnd.min()), int(fnd.max()), float(out.mean())))
 import zlib
-print("checksums: irradiance %08x found %08x" % (zlib.crc32(out.cpu().numpy().tobytes()), zlib.crc32(fnd.cpu().numpy().tobytes())))
+print("checksums: irradiance %08x found %08x r2 %08x" % (zlib.crc32(out.cpu().numpy().tobytes()), zlib.crc32(fnd.cpu().numpy().tobytes()),
+                                                          zlib.crc32(r2o.cpu().numpy().tobytes())))
+if a.dump:
+    np.savez(a.dump, found=fnd.cpu().numpy(), r2=r2o.cpu().numpy(), irr=out.cpu().numpy())
 pm.count_stats(True)
 pm.irradiance_estimate(P, N, nq, out, nphotons=a.k, stream=st)
 w = pm.stats()
 pm.count_stats(False)
-print("per query: " + "  ".join("%s %.2f" % (k, v / nq) for k, v in w.items() if k != "unused"))
+print("per query: " + "  ".join("%s %.2f" % (k, v / nq) for k, v in w.items() if not k.startswith("unused")))

@@ -160,5 +160,18 @@ if m.get("SQC_DCACHE_REQ"): print("scalar cache: hit rate %.3f, misses per reque
 if m.get("SQ_INSTS_SMEM"): print("cycles per SMEM instruction: %.1f" % (m.get("SQ_INST_CYCLES_SMEM", 0) / m["SQ_INSTS_SMEM"]))
 PY
     ;;
+  photon_diff)
+    for v in default _kd; do
+      d=lib$v; [ "$v" = default ] && d=lib
+      MIRO_LIB=$LIB/$d/libmiro_hip.so python tools/photon_probe.py --reps 1 --random-queries 20000 --dump $out/q$v.npz 2>&1 | grep "checksums\|queries, k"
+    done
+    python3 - <<'PY'
+import numpy as np
+a = np.load("gpurun_out/r03_photon_diff/qdefault.npz"); b = np.load("gpurun_out/r03_photon_diff/q_kd.npz")
+bad = np.nonzero(a["r2"].view(np.uint32) != b["r2"].view(np.uint32))[0]
+print("r2 differs on", len(bad), "of", len(a["r2"]), "; found differs on", int((a["found"] != b["found"]).sum()))
+for i in bad[:12]: print(i, i % 64, "boxed", a["r2"][i], a["found"][i], "kd", b["r2"][i], b["found"][i], "ratio", a["r2"][i] / b["r2"][i])
+PY
+    ;;
   *) echo "unknown stage $stage"; exit 2 ;;
 esac
