@@ -161,6 +161,17 @@ __device__ __forceinline__ int first_overflow(const PhotonMapDev &pm, float qx, 
                                               float md2, int k, float &radius_after, unsigned &visits) {
     radius_after = md2;
     if (pm.n < 1) return 0;
+    // max_dist is 1e10 in the reference (Miro.h:17): larger than any distance between the query and a photon.  When the whole
+    // map's box lies inside max_dist of the query, so does every splitting plane, and "the far child if the plane is inside
+    // max_dist" (:168-172) needs no look at the plane -- one record fetch less per far-side step of a walk that is bound by them.
+    bool all_inside;
+    {
+        const float4 lo = pm.boxes[2], hi = pm.boxes[3];                 // box of everything below the root
+        const float ex = fmaxf(fabsf(qx - lo.x), fabsf(qx - hi.x)), ey = fmaxf(fabsf(qy - lo.y), fabsf(qy - hi.y)),
+                    ez = fmaxf(fabsf(qz - lo.z), fabsf(qz - hi.z));
+        const float far2 = fmaxf(ex, fmaxf(ey, ez));
+        all_inside = far2 * far2 < md2;                                  // side * side <= far2 * far2 for every plane (monotone)
+    }
     int i = 1, cnt = 0, best_i = 0;
     float best_d2 = -1.0f, second_d2 = -1.0f;
     unsigned near_right = 0;              // bit d: at the ancestor of depth d the near child was the right one
@@ -200,6 +211,7 @@ __device__ __forceinline__ int first_overflow(const PhotonMapDev &pm, float qx, 
         const int d = 31 - __clz(parent);
         const bool was_near = (unsigned)(i & 1) == ((near_right >> d) & 1u);
         descend = false;
+        if (was_near && all_inside) { i ^= 1; descend = true; continue; }      // every plane is inside max_dist: no need to look
         if (was_near) {
             const float4 A = pm.posplane[parent];
             const int plane = __float_as_int(A.w);
