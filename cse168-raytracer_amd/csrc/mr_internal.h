@@ -189,8 +189,9 @@ mr_status launch_level(const DeviceScene &ds, const mr_level_desc &ld, const mr_
 
 // photon map on the device: three float4 planes in kd-tree heap order, 1-based (children of i: 2i, 2i+1)
 struct PhotonMapDev {
-    float4 *posplane = nullptr;   // (x, y, z, split axis as int bits)
-    float4 *dir = nullptr;        // incoming direction de-quantised through the reference's tables
+    float4 *rec = nullptr;        // two per photon, one 32-byte record: (x, y, z, split axis as int bits), then the incoming
+                                  // direction de-quantised through the reference's tables -- both halves in one cache line for the
+                                  // divergent fetches of the reference-order pre-pass
     float4 *power = nullptr;      // (r, g, b, -)
     int32_t n = 0, half = 0;      // stored photons; nodes with index < half descend (PhotonMap.cpp:160,357)
     // Bounding boxes of the tree's BLOCKS (the 63 nodes of six levels below a block root r = 64^L + i, L = 0 .. layers - 1):

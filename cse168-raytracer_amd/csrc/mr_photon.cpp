@@ -120,7 +120,7 @@ struct Balancer {
 };
 
 void release(mr_photon_map *m) {
-    (void)hipFree(m->dev.posplane); (void)hipFree(m->dev.dir); (void)hipFree(m->dev.power); (void)hipFree(m->dev.boxes); (void)hipFree(m->d_stats);
+    (void)hipFree(m->dev.rec); (void)hipFree(m->dev.power); (void)hipFree(m->dev.boxes); (void)hipFree(m->d_stats);
     m->dev = PhotonMapDev();
     m->d_stats = nullptr;
     m->on_device = false;
@@ -217,11 +217,11 @@ mr_status mr_photon_map_balance(mr_photon_map *m, uint32_t host_only) {
     }
     a[0] = d[0] = p[0] = make_float4(0, 0, 0, 0);
     const size_t bytes = (size_t)(n + 1) * sizeof(float4);
-    MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->dev.posplane), bytes));
-    MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->dev.dir), bytes));
+    std::vector<float4> rec(2 * (size_t)(n + 1));
+    for (uint32_t i = 0; i <= n; i++) { rec[2 * (size_t)i] = a[i]; rec[2 * (size_t)i + 1] = d[i]; }
+    MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->dev.rec), 2 * bytes));
     MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->dev.power), bytes));
-    MR_HIP_CHECK(hipMemcpy(m->dev.posplane, a.data(), bytes, hipMemcpyHostToDevice));
-    MR_HIP_CHECK(hipMemcpy(m->dev.dir, d.data(), bytes, hipMemcpyHostToDevice));
+    MR_HIP_CHECK(hipMemcpy(m->dev.rec, rec.data(), 2 * bytes, hipMemcpyHostToDevice));
     MR_HIP_CHECK(hipMemcpy(m->dev.power, p.data(), bytes, hipMemcpyHostToDevice));
     m->dev.n = (int32_t)n;
     m->dev.half = (int32_t)n / 2 - 1;                               // half_stored_photons, PhotonMap.cpp:357

@@ -178,7 +178,7 @@ __device__ __forceinline__ int first_overflow(const PhotonMapDev &pm, float qx, 
     bool descend = true;
     while (true) {
         if (descend && i < pm.half) {                                       // :160-172, going down
-            const float4 A = pm.posplane[i];
+            const float4 A = pm.rec[2 * i];
             const int plane = __float_as_int(A.w);
             const float side = (plane == 0 ? qx : (plane == 1 ? qy : qz)) - (plane == 0 ? A.x : (plane == 1 ? A.y : A.z));
             const int d = 31 - __clz(i);
@@ -190,7 +190,7 @@ __device__ __forceinline__ int first_overflow(const PhotonMapDev &pm, float qx, 
         // the photon at node i (:177-186)
         {
             visits++;
-            const float4 A = pm.posplane[i], D = pm.dir[i];
+            const float4 A = pm.rec[2 * i], D = pm.rec[2 * i + 1];
             float dd = A.x - qx;
             float d2 = dd * dd;
             dd = A.y - qy; d2 += dd * dd;
@@ -213,7 +213,7 @@ __device__ __forceinline__ int first_overflow(const PhotonMapDev &pm, float qx, 
         descend = false;
         if (was_near && all_inside) { i ^= 1; descend = true; continue; }      // every plane is inside max_dist: no need to look
         if (was_near) {
-            const float4 A = pm.posplane[parent];
+            const float4 A = pm.rec[2 * parent];
             const int plane = __float_as_int(A.w);
             const float side = (plane == 0 ? qx : (plane == 1 ? qy : qz)) - (plane == 0 ? A.x : (plane == 1 ? A.y : A.z));
             if (side * side < md2) { i ^= 1; descend = true; continue; }
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(STATS ? 
                 }
                 vb[u] = go[u] && node_lane && jb[u] <= pm.n;
                 Ab[u] = make_float4(0.f, 0.f, 0.f, 0.f); Db[u] = Ab[u];
-                if (vb[u]) { Ab[u] = pm.posplane[jb[u]]; Db[u] = pm.dir[jb[u]]; }
+                if (vb[u]) { Ab[u] = pm.rec[2 * jb[u]]; Db[u] = pm.rec[2 * jb[u] + 1]; }
             }
 #pragma unroll
             for (int u = 0; u < kExamine; u++) {
