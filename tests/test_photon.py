@@ -204,3 +204,75 @@ def test_photons_below_the_last_descending_node_are_never_found(oracle, miro, n)
     half = n // 2 - 1
     unreachable = (last // 2) >= half
     assert unreachable.any() and not unreachable.all()
+
+
+PHOTON_FUZZ_SEEDS = int(__import__("os").environ.get("MIRO_PHOTON_FUZZ_SEEDS", "24"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(PHOTON_FUZZ_SEEDS))
+def test_photon_search_fuzz(oracle, miro, seed):
+    """Differential fuzzing of mr_irradiance_estimate against the oracle's restated locate_photons: random map sizes (1 ... 70 000:
+    one, two and three layers of blocks, ragged last levels), k from 1 to 512, max_dist from "a handful of photons" to the
+    reference's 1e10, photon positions on a coarse grid (exact distance ties, coincident photons, duplicates) or generic, clustered
+    or spread; queries on photons, between them, far outside the map, in runs of neighbours (the guessed radius) and scattered
+    (its fallback).  `found` and the radius np.dist2[0] must be the oracle's on every query; powers are uniform, so the irradiance
+    does not depend on which of several photons at exactly the same distance is kept (PARITY UNPINNED like the rest of this file:
+    the oracle is a restatement)."""
+    import torch
+    rng = np.random.default_rng(4242 + seed)
+    n = int(rng.choice([1, 2, 3, 63, 64, 65, 130, 1000, 4095, 4096, 4200, 20000, 70000]))
+    if rng.random() < 0.5:
+        n = max(1, n + int(rng.integers(-3, 4)))
+    k = int(rng.choice([1, 2, 7, 50, 200, 500, 512]))
+    grid = rng.random() < 0.6
+    span = float(rng.choice([1.0, 8.0, 100.0]))
+    if grid:
+        step = span / float(rng.choice([4, 16, 64]))
+        pos = (rng.integers(0, int(span / step) + 1, (n, 3)) * step).astype(np.float32)
+        if rng.random() < 0.5:
+            pos[:, int(rng.integers(0, 3))] = 0.0                      # a plane of photons: the tree splits on two axes only
+    else:
+        pos = (rng.random((n, 3)) * span).astype(np.float32)
+        if rng.random() < 0.4:                                         # clusters
+            pos = (pos[rng.integers(0, max(1, n // 50), n)] + rng.normal(0, span * 1e-3, (n, 3))).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-20).astype(np.float32)
+    if rng.random() < 0.3:
+        d[:] = d[0]                                                    # every photon faces the same way
+    pw = np.full((n, 3), 0.25, np.float32)
+    a, b = oracle.PhotonMap(n + 3), miro.PhotonMap(n + 3)
+    for m in (a, b):
+        m.store(pw, pos, d)
+        m.scale_photon_power(1.0 / n)
+    a.balance()
+    b.balance()
+    nq = 640
+    base = pos[rng.integers(0, n, nq)]
+    kind = rng.integers(0, 4, nq)
+    q = base.copy()
+    q[kind == 1] += rng.normal(0, span * 0.01, (int((kind == 1).sum()), 3)).astype(np.float32)
+    q[kind == 2] = (rng.random((int((kind == 2).sum()), 3)) * span * 3 - span).astype(np.float32)      # also outside the map
+    run = np.cumsum(rng.normal(0, span * 1e-3, (nq, 3)), axis=0).astype(np.float32)                    # neighbours: a random walk
+    q[kind == 3] = (pos[0] + run)[kind == 3]
+    qn = -d[rng.integers(0, n, nq)]
+    flip = rng.random(nq) < 0.2
+    qn[flip] = rng.normal(size=(int(flip.sum()), 3)).astype(np.float32)
+    qn /= np.maximum(np.linalg.norm(qn, axis=1, keepdims=True), 1e-20).astype(np.float32)
+    mds = [1e10, float(span * rng.choice([0.02, 0.1, 0.5]))]
+    for md in mds:
+        want, found, r2 = a.irradiance_estimate(q, qn, max_dist=md, nphotons=k)
+        out = torch.empty((nq, 3), dtype=torch.float32, device="cuda")
+        df = torch.empty(nq, dtype=torch.int32, device="cuda")
+        dr = torch.empty(nq, dtype=torch.float32, device="cuda")
+        b.irradiance_estimate(torch.from_numpy(q).cuda(), torch.from_numpy(qn).cuda(), nq, out, max_dist=md, nphotons=k, d_found=df, d_r2=dr)
+        torch.cuda.synchronize()
+        gf, gr = df.cpu().numpy(), dr.cpu().numpy()
+        bad = np.nonzero((gf != found) | (gr.view(np.uint32) != r2.view(np.uint32)))[0]
+        assert bad.size == 0, "n=%d k=%d md=%g grid=%s: first mismatches %s: found %s vs %s, r2 %s vs %s" % (
+            n, k, md, grid, bad[:5], gf[bad[:5]], found[bad[:5]], gr[bad[:5]], r2[bad[:5]])
+        got = out.cpu().numpy()
+        fin = np.isfinite(want)                                        # a radius of 0 (query on a photon, k = 1) divides by zero on both sides
+        assert np.array_equal(np.isfinite(got), fin)
+        scale = max(float(np.abs(want[fin]).max()) if fin.any() else 0.0, 1e-30)
+        assert np.abs(got[fin] - want[fin]).max() <= 2e-5 * scale if fin.any() else True
