@@ -551,6 +551,7 @@ mr_status mr_trace(mr_scene *s, const mr_ray *rays, uint64_t n, mr_hit *hits, ui
     p.rays = d_rays; p.hits = d_hits; p.n = n; p.n_dev = nullptr; p.stats = s->d_stats;
     p.planes = s->dev.planes; p.n_planes = s->dev.n_planes; p.n_spheres = s->dev.n_spheres;
     p.work_counter = s->d_work_counters + (s->next_counter.fetch_add(1) % kWorkCounters);
+    p.order = nullptr;
     if (staged.owns_lock() && n > kStageChunk) {
         // host buffers, large batch: chunk k+1 uploads and chunk k-1 downloads while chunk k is traced (full overlap when
         // the caller's buffers are pinned -- mr_host_alloc --, since only then are the copies asynchronous to this thread)
@@ -628,7 +629,37 @@ mr_status mr_trace_indirect(mr_scene *s, const mr_ray *d_rays, const uint64_t *d
     p.stats = s->d_stats;
     p.planes = s->dev.planes; p.n_planes = s->dev.n_planes; p.n_spheres = s->dev.n_spheres;
     p.work_counter = s->d_work_counters + (s->next_counter.fetch_add(1) % kWorkCounters);
+    p.order = nullptr;
     return launch_trace(p, flags, static_cast<hipStream_t>(stream_v));
+}
+
+mr_status mr_trace_grouped(mr_scene *s, const mr_ray *d_rays, uint64_t n, mr_hit *d_hits, uint32_t *d_order, uint32_t chunk_log2,
+                           uint32_t flags, void *stream_v) {
+    mr_status st = require_device(s);
+    if (st != MR_OK) return st;
+    if (n == 0) return MR_OK;
+    if (!d_rays || !d_hits || !d_order) return fail(MR_ERR_INVALID, "NULL argument");
+    if ((reinterpret_cast<uintptr_t>(d_rays) & 15) || (reinterpret_cast<uintptr_t>(d_hits) & 15) || (reinterpret_cast<uintptr_t>(d_order) & 3))
+        return fail(MR_ERR_INVALID, "device ray/hit buffers must be 16-byte aligned, the order buffer 4-byte aligned");
+    if (flags & (MR_MATH_FAST | MR_COUNT_STATS))
+        return fail(MR_ERR_INVALID, "mr_trace_grouped: flags may hold MR_TRACE_ANY, MR_MATH_PRODUCT, MR_TRACE_INCOHERENT only");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    MR_HIP_CHECK(hipSetDevice(s->device));
+    if (chunk_log2 == 0) chunk_log2 = 14;
+    st = launch_octant_order(d_rays, n, chunk_log2, d_order, stream);
+    if (st != MR_OK) return st;
+    TraceParams p;
+    p.nodes = s->dev.nodes; p.tris = s->dev.tris; p.tri_prim = s->dev.tri_prim; p.leaf_cnt_ext = s->dev.leaf_cnt_ext;
+    memcpy(p.root_lo, s->dev.root_lo, sizeof(p.root_lo));
+    memcpy(p.root_hi, s->dev.root_hi, sizeof(p.root_hi));
+    p.root_ref = s->dev.root_ref;
+    p.stack_depth = (int32_t)s->dev.stack_depth;
+    p.rays = d_rays; p.hits = d_hits; p.n = n; p.n_dev = nullptr;
+    p.stats = s->d_stats;
+    p.planes = s->dev.planes; p.n_planes = s->dev.n_planes; p.n_spheres = s->dev.n_spheres;
+    p.work_counter = nullptr;
+    p.order = d_order;
+    return launch_trace(p, flags & ~(uint32_t)(MR_RAYS_ON_DEVICE | MR_HITS_ON_DEVICE | MR_TRACE_PERSISTENT), stream);
 }
 
 mr_status mr_trace_get_stats(mr_scene *s, uint64_t *box_tests, uint64_t *tri_tests, int32_t reset) {

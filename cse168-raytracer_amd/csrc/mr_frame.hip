@@ -235,7 +235,7 @@ mr_status MR_FRAME_ENTRY(const DeviceScene &ds, const mr_frame_desc &fd, float *
     p.stack_depth = (int32_t)ds.stack_depth;
     p.rays = nullptr; p.hits = nullptr; p.n = a.eye.n; p.n_dev = nullptr; p.stats = nullptr;
     p.planes = ds.planes; p.n_planes = ds.n_planes; p.n_spheres = ds.n_spheres;
-    p.work_counter = nullptr;
+    p.work_counter = nullptr; p.order = nullptr;
     a.m = surface_ptrs(ds);
     for (int c = 0; c < 3; c++) {
         a.lt.L[c] = fd.light.position[c]; a.lt.color[c] = fd.light.color[c]; a.lt.diffuse[c] = fd.diffuse[c]; a.lt.bg[c] = 0.0f;

@@ -126,9 +126,12 @@ struct TraceParams {
     const float4 *planes;                 // unbounded objects, scanned after the BVH (Scene.cpp:220-230)
     uint32_t n_planes, n_spheres;
     unsigned long long *work_counter;     // zeroed per launch: ray hand-out counter of the persistent kernel
+    const uint32_t *order;                // optional: lane k traces ray order[k] (and writes hits[order[k]]): mr_trace_grouped
 };
 
 mr_status launch_trace(const TraceParams &p, uint32_t flags, hipStream_t stream);
+// order[] = the batch's ray indices, grouped by direction octant inside consecutive chunks of 2^chunk_log2 rays (mr_kernels.hip)
+mr_status launch_octant_order(const mr_ray *d_rays, unsigned long long n, uint32_t chunk_log2, uint32_t *d_order, hipStream_t stream);
 mr_status launch_eye_rays(const mr_camera &cam, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,
                           uint32_t spp, uint32_t jitter, uint32_t seed, bool tiled, mr_ray *d_rays, hipStream_t stream);
 mr_status launch_shadow_rays(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits,

@@ -47,9 +47,11 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(TraceParams p) {
         const bool live = idx < n_rays;
         // two dwordx4 loads per lane, 32-byte stride: every byte of the fetched lines is used
         float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(1.f, 1.f, 1.f, -1.f);
+        unsigned long long src = idx;                     // mr_trace_grouped: the lane's ray is order[idx], its hit goes to hits[order[idx]]
+        if (live && p.order) src = p.order[idx];
         if (live) {
-            ra = reinterpret_cast<const float4 *>(p.rays)[2 * idx];
-            rb = reinterpret_cast<const float4 *>(p.rays)[2 * idx + 1];
+            ra = reinterpret_cast<const float4 *>(p.rays)[2 * src];
+            rb = reinterpret_cast<const float4 *>(p.rays)[2 * src + 1];
         }
         RayRegs r;
         ray_setup(r, ra, rb);
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(TraceParams p) {
         trace_ray<EXACT, ANY, STATS, VAR>(p, r, rb.w, live, L, plane_hit, s_stack, tid, st);
         if (live) {
             const mr_hit h = make_hit<(VAR & 32) != 0>(p, L, plane_hit, rb.w);
-            reinterpret_cast<float4 *>(p.hits)[idx] = *reinterpret_cast<const float4 *>(&h);
+            reinterpret_cast<float4 *>(p.hits)[src] = *reinterpret_cast<const float4 *>(&h);
         }
     }
 
@@ -71,6 +73,69 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(TraceParams p) {
         if ((tid & 63) == 0) {
             atomicAdd(&p.stats[0], st.box);
             atomicAdd(&p.stats[1], st.tri);
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Ray order for bounce queues (mr_trace_grouped).  A generator writes its children in the order of their parents: the
+// origins of neighbouring rays are neighbouring surface points, their directions are drawn independently -- the 64 rays
+// of a wave point into all eight octants, run the generic slab tests, and a wave lasts as long as its unluckiest lane.
+// Grouping the rays of a chunk by octant keeps the origins coherent and makes whole waves share a direction sign: the
+// octant-specialised loops apply, and rays that leave the scene at once (the bunny's upward bounces) stop holding waves.
+// order[] is a permutation inside each chunk of 2^chunk_log2 rays: stable counting sort on the octant (sign bits of d);
+// no ray is moved -- the trace kernel gathers through the index (two 16-byte loads per lane either way).
+// One workgroup per chunk, a wave owns a contiguous quarter of it; octants are kept as 3-bit fields in registers.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kOrderMaxChunkLog2 = 14;    // chunks of up to 16 384 rays (one octant byte per ray in LDS)
+__global__ __launch_bounds__(kBlock) void octant_order_kernel(const mr_ray *rays, unsigned long long n, uint32_t chunk_log2, uint32_t *order) {
+    __shared__ unsigned s_cnt[kBlock / 64][8];
+    __shared__ unsigned char s_oct[1 << kOrderMaxChunkLog2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long chunk = 1ull << chunk_log2, base = (unsigned long long)blockIdx.x * chunk;
+    const unsigned per_wave = (unsigned)(chunk / (kBlock / 64)), iters = per_wave / 64u;      // chunk >= 256
+    const unsigned wfirst = (unsigned)wave * per_wave;          // a wave owns a contiguous quarter: the sort is stable
+    unsigned cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};                 // wave totals (uniform)
+    for (unsigned it = 0; it < iters; it++) {
+        const unsigned local = wfirst + it * 64u + (unsigned)lane;
+        const unsigned long long idx = base + local;
+        unsigned oct = 8;                                       // 8: no ray here
+        if (idx < n) {
+            const float4 rb = reinterpret_cast<const float4 *>(rays)[2 * idx + 1];
+            oct = (rb.x < 0.0f ? 1u : 0u) | (rb.y < 0.0f ? 2u : 0u) | (rb.z < 0.0f ? 4u : 0u);
+        }
+        s_oct[local] = (unsigned char)oct;                      // read back by the same lane below
+#pragma unroll
+        for (int o = 0; o < 8; o++) cnt[o] += (unsigned)__popcll(__ballot(oct == (unsigned)o));
+    }
+    if (lane < 8) {
+        unsigned c = 0;
+#pragma unroll
+        for (int o = 0; o < 8; o++) c = lane == o ? cnt[o] : c;
+        s_cnt[wave][lane] = c;
+    }
+    __syncthreads();
+    // where this wave's rays of octant o start: all rays of smaller octants, then the same octant's rays of earlier waves
+    unsigned off[8];
+    {
+        unsigned run = 0;
+#pragma unroll
+        for (int o = 0; o < 8; o++) {
+            unsigned before = 0, total = 0;
+            for (int w = 0; w < kBlock / 64; w++) { const unsigned c = s_cnt[w][o]; total += c; if (w < wave) before += c; }
+            off[o] = run + before;
+            run += total;
+        }
+    }
+    for (unsigned it = 0; it < iters; it++) {
+        const unsigned local = wfirst + it * 64u + (unsigned)lane;
+        const unsigned oct = s_oct[local];
+#pragma unroll
+        for (int o = 0; o < 8; o++) {
+            const unsigned long long m = __ballot(oct == (unsigned)o);
+            if (oct == (unsigned)o) order[base + off[o] + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(base + local);
+            off[o] += (unsigned)__popcll(m);
         }
     }
 }
@@ -381,8 +446,20 @@ static mr_status launch_product(const TraceParams &p, hipStream_t stream) {
 }
 #endif
 
+mr_status launch_octant_order(const mr_ray *d_rays, unsigned long long n, uint32_t chunk_log2, uint32_t *d_order, hipStream_t stream) {
+    if (n == 0) return MR_OK;
+    if (chunk_log2 < 8 || chunk_log2 > (uint32_t)kOrderMaxChunkLog2) return fail(MR_ERR_INVALID, "ray order: chunks of 2^8 ... 2^%d rays", kOrderMaxChunkLog2);
+    if (n > 0xFFFFFFFFull) return fail(MR_ERR_INVALID, "ray order: at most 2^32 - 1 rays per batch (32-bit indices)");
+    const unsigned long long chunks = (n + (1ull << chunk_log2) - 1) >> chunk_log2;
+    hipLaunchKernelGGL(octant_order_kernel, dim3((unsigned)chunks), dim3(kBlock), 0, stream, d_rays, n, chunk_log2, d_order);
+    MR_HIP_CHECK(hipGetLastError());
+    return MR_OK;
+}
+
 mr_status launch_trace(const TraceParams &p, uint32_t flags, hipStream_t stream) {
     if (p.n == 0) return MR_OK;
+    // a ray order (mr_trace_grouped) is gathered by the one-shot kernels only
+    if (p.order) flags &= ~(uint32_t)MR_TRACE_PERSISTENT;
     const bool fast = flags & MR_MATH_FAST, any = flags & MR_TRACE_ANY, stats = flags & MR_COUNT_STATS;
     const bool product = flags & MR_MATH_PRODUCT, vote = flags & MR_TRACE_INCOHERENT;
     if (p.n_planes || p.n_spheres) {

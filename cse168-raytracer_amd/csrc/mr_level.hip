@@ -194,7 +194,7 @@ mr_status launch_level(const DeviceScene &ds, const mr_level_desc &ld, const mr_
     p.stack_depth = (int32_t)ds.stack_depth;
     p.rays = d_rays; p.hits = nullptr; p.n = n; p.n_dev = nullptr; p.stats = nullptr;
     p.planes = ds.planes; p.n_planes = ds.n_planes; p.n_spheres = ds.n_spheres;
-    p.work_counter = nullptr;
+    p.work_counter = nullptr; p.order = nullptr;
     a.m = mesh_of(ds);
     for (int c = 0; c < 3; c++) { a.lt.L[c] = ld.light.position[c]; a.lt.color[c] = ld.light.color[c]; }
     a.lt.wattage = ld.light.wattage;

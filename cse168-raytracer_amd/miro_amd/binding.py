@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "mr_scene_create", "mr_scene_destroy", "mr_scene_add_mesh", "mr_scene_add_obj", "mr_scene_add_triangle",
     "mr_scene_add_sphere", "mr_scene_add_plane",
     "mr_bvh_build", "mr_scene_get_info", "mr_scene_get_mesh", "mr_scene_export_tree",
-    "mr_trace", "mr_host_alloc", "mr_host_free", "mr_trace_indirect", "mr_trace_get_stats", "mr_gen_eye_rays", "mr_gen_eye_rays_tiled", "mr_tile_pixel_map", "mr_untile_pixels", "mr_gen_shadow_rays", "mr_hit_attrs",
+    "mr_trace", "mr_host_alloc", "mr_host_free", "mr_trace_indirect", "mr_trace_grouped", "mr_trace_get_stats", "mr_gen_eye_rays", "mr_gen_eye_rays_tiled", "mr_tile_pixel_map", "mr_untile_pixels", "mr_gen_shadow_rays", "mr_hit_attrs",
     "mr_shade_direct", "mr_render_direct", "mr_band_locate", "mr_band_rows_of", "mr_deinterleave_bands", "mr_gen_path_rays", "mr_trace_level", "mr_tonemap",
     "mr_scene_set_materials", "mr_shade_accumulate", "mr_gen_secondary_rays",
     "mr_photon_map_create", "mr_photon_map_destroy", "mr_photon_map_store", "mr_photon_map_scale",
@@ -144,6 +144,7 @@ def load_library(path=None):
     L.mr_scene_export_tree.argtypes = [vp, f32p, C.POINTER(C.c_int32), u32p]
     L.mr_trace.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp]
     L.mr_trace_indirect.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_uint32, vp]
+    L.mr_trace_grouped.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint32, C.c_uint32, vp]
     L.mr_host_alloc.argtypes = [C.POINTER(vp), C.c_uint64]
     L.mr_host_free.argtypes = [vp]
     L.mr_trace_get_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]
@@ -377,6 +378,12 @@ class Scene:
         """Batch size read on the device from d_count (uint64/int64 tensor written by gen_shadow_rays)."""
         _check(self.L.mr_trace_indirect(self.h, d_rays.data_ptr(), d_count.data_ptr(), max_rays, d_hits.data_ptr(),
                                         flags, _stream_ptr(stream)))
+
+    def trace_grouped(self, d_rays, n, d_hits, d_order, flags=0, chunk_log2=0, stream=None):
+        """mr_trace_grouped: a bounce queue traced with its rays grouped by direction octant inside chunks of 2^chunk_log2
+        (d_order: int32 / uint32 tensor of n entries, written by the call); the hit buffer is mr_trace's."""
+        _check(self.L.mr_trace_grouped(self.h, d_rays.data_ptr(), n, d_hits.data_ptr(), d_order.data_ptr(), chunk_log2, flags,
+                                       _stream_ptr(stream)))
 
     def stats(self, reset=True):
         a, b = C.c_uint64(0), C.c_uint64(0)

@@ -637,3 +637,36 @@ def test_storage_layouts_give_identical_hit_records(miro, layout):
                     if flags == miro.MR_COUNT_STATS:
                         outs[-1] += repr(s.stats()).encode()
                 assert outs[0] == outs[1], (name, flags)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["sponza", "spiral"])
+def test_grouped_trace_returns_the_plain_traces_hit_buffer(miro, name):
+    """mr_trace_grouped orders a batch by direction octant inside chunks (a permutation: every index exactly once, octants
+    ascending inside a chunk, original order inside an octant) and traces through the index: the hit buffer is mr_trace's byte
+    for byte -- ragged batch sizes, every chunk size, default / voting / product / any-hit kernels, triangles and spheres."""
+    import torch
+    from miro_amd import scenes as sc_mod
+    s = product_scene(miro, name)
+    v = s.arrays()[0]
+    for n, lg in ((1, 8), (255, 8), (4097, 8), (100003, 11), (100003, 14), (70000, 0)):
+        rnd = random_rays(miro.RAY_DTYPE, n, v.min(0), v.max(0), seed=n)
+        rnd["dx"][::7] = 0.0                                         # zero components sit in the "non-negative" octants
+        d_r = torch.from_numpy(rnd.view(np.float32).reshape(-1, 8).copy()).cuda()
+        order = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        for flags in (0, miro.MR_TRACE_INCOHERENT, miro.MR_MATH_PRODUCT, miro.MR_TRACE_ANY):
+            ref = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+            got = torch.full((n, 4), 7.0, dtype=torch.float32, device="cuda")
+            s.trace_device(d_r, n, ref, flags)
+            s.trace_grouped(d_r, n, got, order, flags, chunk_log2=lg)
+            torch.cuda.synchronize()
+            assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (n, lg, flags)
+        o = order.cpu().numpy().astype(np.int64)
+        assert np.array_equal(np.sort(o), np.arange(n))             # a permutation
+        chunk = 1 << (lg or 14)
+        octs = ((rnd["dx"] < 0).astype(np.int64) | ((rnd["dy"] < 0).astype(np.int64) << 1) | ((rnd["dz"] < 0).astype(np.int64) << 2))[o]
+        for c0 in range(0, n, chunk):
+            oc, oi = octs[c0:c0 + chunk], o[c0:c0 + chunk]
+            assert (oi // chunk == c0 // chunk).all()               # ... inside each chunk
+            assert (np.diff(oc) >= 0).all()                         # octants ascending
+            assert (np.diff(oi)[np.diff(oc) == 0] > 0).all()        # stable inside an octant
