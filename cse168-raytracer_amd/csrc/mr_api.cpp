@@ -633,8 +633,20 @@ mr_status mr_trace_indirect(mr_scene *s, const mr_ray *d_rays, const uint64_t *d
     return launch_trace(p, flags, static_cast<hipStream_t>(stream_v));
 }
 
-mr_status mr_trace_grouped(mr_scene *s, const mr_ray *d_rays, uint64_t n, mr_hit *d_hits, uint32_t *d_order, uint32_t chunk_log2,
-                           uint32_t flags, void *stream_v) {
+mr_status mr_order_by_octant(mr_scene *s, const mr_ray *d_rays, const uint8_t *d_octants, uint64_t n, uint32_t chunk_log2,
+                             uint32_t *d_order, void *stream) {
+    mr_status st = require_device(s);
+    if (st != MR_OK) return st;
+    if (n == 0) return MR_OK;
+    if ((!d_rays && !d_octants) || !d_order) return fail(MR_ERR_INVALID, "NULL argument");
+    if ((reinterpret_cast<uintptr_t>(d_rays) & 15) || (reinterpret_cast<uintptr_t>(d_order) & 3))
+        return fail(MR_ERR_INVALID, "the ray buffer must be 16-byte aligned, the order buffer 4-byte aligned");
+    MR_HIP_CHECK(hipSetDevice(s->device));
+    return launch_octant_order(d_rays, d_octants, n, chunk_log2 ? chunk_log2 : 14u, d_order, static_cast<hipStream_t>(stream));
+}
+
+mr_status mr_trace_grouped(mr_scene *s, const mr_ray *d_rays, const uint8_t *d_octants, uint64_t n, mr_hit *d_hits, uint32_t *d_order,
+                           uint32_t chunk_log2, uint32_t flags, void *stream_v) {
     mr_status st = require_device(s);
     if (st != MR_OK) return st;
     if (n == 0) return MR_OK;
@@ -645,9 +657,11 @@ mr_status mr_trace_grouped(mr_scene *s, const mr_ray *d_rays, uint64_t n, mr_hit
         return fail(MR_ERR_INVALID, "mr_trace_grouped: flags may hold MR_TRACE_ANY, MR_MATH_PRODUCT, MR_TRACE_INCOHERENT only");
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     MR_HIP_CHECK(hipSetDevice(s->device));
-    if (chunk_log2 == 0) chunk_log2 = 14;
-    st = launch_octant_order(d_rays, n, chunk_log2, d_order, stream);
-    if (st != MR_OK) return st;
+    if (!(chunk_log2 & MR_ORDER_GIVEN)) {
+        if (chunk_log2 == 0) chunk_log2 = 14;
+        st = launch_octant_order(d_rays, d_octants, n, chunk_log2, d_order, stream);
+        if (st != MR_OK) return st;
+    }
     TraceParams p;
     p.nodes = s->dev.nodes; p.tris = s->dev.tris; p.tri_prim = s->dev.tri_prim; p.leaf_cnt_ext = s->dev.leaf_cnt_ext;
     memcpy(p.root_lo, s->dev.root_lo, sizeof(p.root_lo));
@@ -849,7 +863,7 @@ mr_status mr_shade_accumulate(mr_scene *s, const mr_ray *d_rays, const mr_hit *d
 
 mr_status mr_gen_secondary_rays(mr_scene *s, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
                                 const uint32_t *d_pixels, uint64_t n, uint32_t spp, mr_ray *d_out_rays, float *d_out_weights,
-                                uint32_t *d_out_pixels, uint64_t *d_count, uint64_t out_capacity, void *stream) {
+                                uint32_t *d_out_pixels, uint64_t *d_count, uint64_t out_capacity, uint8_t *d_out_octants, void *stream) {
     mr_status st = require_device(s);
     if (st != MR_OK) return st;
     if (!d_rays || !d_hits || !d_out_rays || !d_out_weights || !d_out_pixels || !d_count) return fail(MR_ERR_INVALID, "NULL argument");
@@ -858,13 +872,13 @@ mr_status mr_gen_secondary_rays(mr_scene *s, const mr_ray *d_rays, const mr_hit 
     if (out_capacity == 0 && n > 0) return fail(MR_ERR_INVALID, "mr_gen_secondary_rays: out_capacity is 0 (room for 3n rays always suffices)");
     MR_HIP_CHECK(hipSetDevice(s->device));
     return launch_secondary_rays(s->dev, d_rays, d_hits, d_weights, d_pixels, n, spp, d_out_rays, d_out_weights, d_out_pixels,
-                                 reinterpret_cast<unsigned long long *>(d_count), out_capacity, static_cast<hipStream_t>(stream));
+                                 reinterpret_cast<unsigned long long *>(d_count), out_capacity, d_out_octants, static_cast<hipStream_t>(stream));
 }
 
 mr_status mr_gen_path_rays(mr_scene *s, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
                            const uint32_t *d_pixels, const uint32_t *d_ids, uint64_t n, uint32_t spp, uint32_t seed,
                            uint32_t bounce, uint32_t kinds, mr_ray *d_out_rays, float *d_out_weights, uint32_t *d_out_pixels,
-                           uint32_t *d_out_ids, uint64_t *d_count, uint64_t out_capacity, void *stream) {
+                           uint32_t *d_out_ids, uint64_t *d_count, uint64_t out_capacity, uint8_t *d_out_octants, void *stream) {
     mr_status st = require_device(s);
     if (st != MR_OK) return st;
     if (!d_rays || !d_hits || !d_out_rays || !d_out_weights || !d_out_pixels || !d_count) return fail(MR_ERR_INVALID, "NULL argument");
@@ -875,7 +889,7 @@ mr_status mr_gen_path_rays(mr_scene *s, const mr_ray *d_rays, const mr_hit *d_hi
     MR_HIP_CHECK(hipSetDevice(s->device));
     return launch_path_rays(s->dev, d_rays, d_hits, d_weights, d_pixels, d_ids, n, spp, seed, bounce, kinds, d_out_rays,
                             d_out_weights, d_out_pixels, d_out_ids, reinterpret_cast<unsigned long long *>(d_count), out_capacity,
-                            static_cast<hipStream_t>(stream));
+                            d_out_octants, static_cast<hipStream_t>(stream));
 }
 
 mr_status mr_trace_level(mr_scene *s, const mr_level_desc *level, const mr_ray *d_rays, const float *d_weights,
@@ -899,6 +913,8 @@ mr_status mr_trace_level(mr_scene *s, const mr_level_desc *level, const mr_ray *
     if ((reinterpret_cast<uintptr_t>(d_rays) & 15) || (reinterpret_cast<uintptr_t>(d_out_rays) & 15) ||
         (reinterpret_cast<uintptr_t>(d_out_count) & 7) || (reinterpret_cast<uintptr_t>(d_counts) & 7))
         return fail(MR_ERR_INVALID, "ray queues must be 16-byte aligned, counters 8-byte aligned");
+    if (level->reserved != 0) return fail(MR_ERR_INVALID, "mr_level_desc.reserved must be 0");
+    if (reinterpret_cast<uintptr_t>(level->d_order) & 3) return fail(MR_ERR_INVALID, "mr_level_desc.d_order must be 4-byte aligned");
     MR_HIP_CHECK(hipSetDevice(s->device));
     return launch_level(s->dev, *level, d_rays, d_weights, d_pixels, d_ids, n, d_rgb, d_out_rays, d_out_weights, d_out_pixels,
                         d_out_ids, reinterpret_cast<unsigned long long *>(d_out_count),

@@ -261,13 +261,13 @@ mr_status launch_shade_accumulate(const DeviceScene &ds, const mr_ray *d_rays, c
 mr_status launch_secondary_rays(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
                                 const uint32_t *d_pixels, unsigned long long n, uint32_t spp, mr_ray *d_out_rays,
                                 float *d_out_weights, uint32_t *d_out_pixels, unsigned long long *d_count,
-                                unsigned long long out_capacity, hipStream_t stream) {
+                                unsigned long long out_capacity, uint8_t *d_out_octants, hipStream_t stream) {
     MR_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), stream));
     if (n == 0) return MR_OK;
     BounceArgs a;
     a.m = mesh_of(ds); a.rays = d_rays; a.hits = d_hits; a.weights = d_weights; a.pixels = d_pixels; a.ids = nullptr;
     a.spp = spp; a.hbase = 0; a.bounce = 0; a.kinds = 0; a.n = n;
-    a.out.rays = d_out_rays; a.out.weights = d_out_weights; a.out.pixels = d_out_pixels; a.out.ids = nullptr; a.out.count = d_count; a.out.capacity = out_capacity;
+    a.out.rays = d_out_rays; a.out.weights = d_out_weights; a.out.pixels = d_out_pixels; a.out.ids = nullptr; a.out.count = d_count; a.out.capacity = out_capacity; a.out.octants = d_out_octants;
     hipLaunchKernelGGL(children_kernel<false>, dim3(grid_for((n + kGenIter - 1) / kGenIter)), dim3(kBlock), 0, stream, a);
     MR_HIP_CHECK(hipGetLastError());
     return MR_OK;
@@ -276,14 +276,14 @@ mr_status launch_secondary_rays(const DeviceScene &ds, const mr_ray *d_rays, con
 mr_status launch_path_rays(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
                            const uint32_t *d_pixels, const uint32_t *d_ids, unsigned long long n, uint32_t spp, uint32_t seed,
                            uint32_t bounce, uint32_t kinds, mr_ray *d_out_rays, float *d_out_weights, uint32_t *d_out_pixels,
-                           uint32_t *d_out_ids, unsigned long long *d_count, unsigned long long out_capacity, hipStream_t stream) {
+                           uint32_t *d_out_ids, unsigned long long *d_count, unsigned long long out_capacity, uint8_t *d_out_octants, hipStream_t stream) {
     MR_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), stream));
     if (n == 0) return MR_OK;
     BounceArgs a;
     a.m = mesh_of(ds); a.rays = d_rays; a.hits = d_hits; a.weights = d_weights; a.pixels = d_pixels; a.ids = d_ids;
     a.spp = spp; a.bounce = bounce; a.kinds = kinds; a.n = n;
     a.hbase = pcg32(seed);
-    a.out.rays = d_out_rays; a.out.weights = d_out_weights; a.out.pixels = d_out_pixels; a.out.ids = d_out_ids; a.out.count = d_count; a.out.capacity = out_capacity;
+    a.out.rays = d_out_rays; a.out.weights = d_out_weights; a.out.pixels = d_out_pixels; a.out.ids = d_out_ids; a.out.count = d_count; a.out.capacity = out_capacity; a.out.octants = d_out_octants;
     hipLaunchKernelGGL(children_kernel<true>, dim3(grid_for((n + kGenIter - 1) / kGenIter)), dim3(kBlock), 0, stream, a);
     MR_HIP_CHECK(hipGetLastError());
     return MR_OK;

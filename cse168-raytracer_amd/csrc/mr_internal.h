@@ -131,7 +131,7 @@ struct TraceParams {
 
 mr_status launch_trace(const TraceParams &p, uint32_t flags, hipStream_t stream);
 // order[] = the batch's ray indices, grouped by direction octant inside consecutive chunks of 2^chunk_log2 rays (mr_kernels.hip)
-mr_status launch_octant_order(const mr_ray *d_rays, unsigned long long n, uint32_t chunk_log2, uint32_t *d_order, hipStream_t stream);
+mr_status launch_octant_order(const mr_ray *d_rays, const uint8_t *d_octants, unsigned long long n, uint32_t chunk_log2, uint32_t *d_order, hipStream_t stream);
 mr_status launch_eye_rays(const mr_camera &cam, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,
                           uint32_t spp, uint32_t jitter, uint32_t seed, bool tiled, mr_ray *d_rays, hipStream_t stream);
 mr_status launch_shadow_rays(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits,
@@ -177,13 +177,13 @@ mr_status launch_shade_accumulate(const DeviceScene &ds, const mr_ray *d_rays, c
 mr_status launch_secondary_rays(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
                                 const uint32_t *d_pixels, unsigned long long n, uint32_t spp, mr_ray *d_out_rays,
                                 float *d_out_weights, uint32_t *d_out_pixels, unsigned long long *d_count,
-                                unsigned long long out_capacity, hipStream_t stream);
+                                unsigned long long out_capacity, uint8_t *d_out_octants, hipStream_t stream);
 
 // PATH_TRACING generators (mr_bounce.hip): kinds bit 0 mirror, 1 refraction pair, 2 diffuse bounce
 mr_status launch_path_rays(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
                            const uint32_t *d_pixels, const uint32_t *d_ids, unsigned long long n, uint32_t spp, uint32_t seed,
                            uint32_t bounce, uint32_t kinds, mr_ray *d_out_rays, float *d_out_weights, uint32_t *d_out_pixels,
-                           uint32_t *d_out_ids, unsigned long long *d_count, unsigned long long out_capacity, hipStream_t stream);
+                           uint32_t *d_out_ids, unsigned long long *d_count, unsigned long long out_capacity, uint8_t *d_out_octants, hipStream_t stream);
 
 mr_status launch_level(const DeviceScene &ds, const mr_level_desc &ld, const mr_ray *d_rays, const float *d_weights,
                        const uint32_t *d_pixels, const uint32_t *d_ids, unsigned long long n, float *d_rgb, mr_ray *d_out_rays,

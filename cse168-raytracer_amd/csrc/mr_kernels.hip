@@ -47,9 +47,8 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(TraceParams p) {
         const bool live = idx < n_rays;
         // two dwordx4 loads per lane, 32-byte stride: every byte of the fetched lines is used
         float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(1.f, 1.f, 1.f, -1.f);
-        unsigned long long src = idx;                     // mr_trace_grouped: the lane's ray is order[idx], its hit goes to hits[order[idx]]
-        if (live && p.order) src = p.order[idx];
-        if (live) {
+        if (live) {                                       // mr_trace_grouped: the lane's ray is order[idx], its hit goes to hits[order[idx]]
+            const unsigned long long src = p.order ? (unsigned long long)p.order[idx] : idx;
             ra = reinterpret_cast<const float4 *>(p.rays)[2 * src];
             rb = reinterpret_cast<const float4 *>(p.rays)[2 * src + 1];
         }
@@ -60,7 +59,9 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(TraceParams p) {
         trace_ray<EXACT, ANY, STATS, VAR>(p, r, rb.w, live, L, plane_hit, s_stack, tid, st);
         if (live) {
             const mr_hit h = make_hit<(VAR & 32) != 0>(p, L, plane_hit, rb.w);
-            reinterpret_cast<float4 *>(p.hits)[src] = *reinterpret_cast<const float4 *>(&h);
+            asm volatile("" ::: "memory");                // the index is read again rather than kept in registers across the traversal
+            const unsigned long long dst = p.order ? (unsigned long long)p.order[idx] : idx;
+            reinterpret_cast<float4 *>(p.hits)[dst] = *reinterpret_cast<const float4 *>(&h);
         }
     }
 
@@ -89,25 +90,40 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(TraceParams p) {
 // One workgroup per chunk, a wave owns a contiguous quarter of it; octants are kept as 3-bit fields in registers.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kOrderMaxChunkLog2 = 14;    // chunks of up to 16 384 rays (one octant byte per ray in LDS)
-__global__ __launch_bounds__(kBlock) void octant_order_kernel(const mr_ray *rays, unsigned long long n, uint32_t chunk_log2, uint32_t *order) {
-    __shared__ unsigned s_cnt[kBlock / 64][8];
+constexpr int kOrderWaves = 16;           // waves of a workgroup, at most (blockDim = 64 * min(16, chunk / 64))
+// BYTES: the octants come from a generator's d_out_octants (one byte per ray: 1/32 of the traffic of reading the rays)
+template <bool BYTES>
+__global__ __launch_bounds__(64 * kOrderWaves) void octant_order_kernel(const mr_ray *rays, const uint8_t *octants, unsigned long long n, uint32_t chunk_log2, uint32_t *order) {
+    __shared__ unsigned s_cnt[kOrderWaves][8];
     __shared__ unsigned char s_oct[1 << kOrderMaxChunkLog2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = (int)(blockDim.x >> 6);
     const unsigned long long chunk = 1ull << chunk_log2, base = (unsigned long long)blockIdx.x * chunk;
-    const unsigned per_wave = (unsigned)(chunk / (kBlock / 64)), iters = per_wave / 64u;      // chunk >= 256
-    const unsigned wfirst = (unsigned)wave * per_wave;          // a wave owns a contiguous quarter: the sort is stable
+    const unsigned per_wave = (unsigned)(chunk / (unsigned)waves), iters = per_wave / 64u;     // chunk >= 64 * waves
+    const unsigned wfirst = (unsigned)wave * per_wave;          // a wave owns a contiguous part: the sort is stable
     unsigned cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};                 // wave totals (uniform)
-    for (unsigned it = 0; it < iters; it++) {
-        const unsigned local = wfirst + it * 64u + (unsigned)lane;
-        const unsigned long long idx = base + local;
-        unsigned oct = 8;                                       // 8: no ray here
-        if (idx < n) {
-            const float4 rb = reinterpret_cast<const float4 *>(rays)[2 * idx + 1];
-            oct = (rb.x < 0.0f ? 1u : 0u) | (rb.y < 0.0f ? 2u : 0u) | (rb.z < 0.0f ? 4u : 0u);
-        }
-        s_oct[local] = (unsigned char)oct;                      // read back by the same lane below
+    for (unsigned it = 0; it < iters; it += 4u) {               // four loads in flight per lane
+        float4 rb[4];
+        unsigned ob[4];
 #pragma unroll
-        for (int o = 0; o < 8; o++) cnt[o] += (unsigned)__popcll(__ballot(oct == (unsigned)o));
+        for (unsigned u = 0; u < 4u; u++) {
+            const unsigned long long idx = base + wfirst + (it + u) * 64u + (unsigned)lane;
+            rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ob[u] = 0;
+            if (it + u < iters && idx < n) {
+                if (BYTES) ob[u] = octants[idx] & 7u;
+                else rb[u] = reinterpret_cast<const float4 *>(rays)[2 * idx + 1];
+            }
+        }
+#pragma unroll
+        for (unsigned u = 0; u < 4u; u++) {
+            if (it + u >= iters) break;
+            const unsigned local = wfirst + (it + u) * 64u + (unsigned)lane;
+            unsigned oct = BYTES ? ob[u] : (rb[u].x < 0.0f ? 1u : 0u) | (rb[u].y < 0.0f ? 2u : 0u) | (rb[u].z < 0.0f ? 4u : 0u);
+            if (base + local >= n) oct = 8;                     // 8: no ray here
+            s_oct[local] = (unsigned char)oct;                  // read back by the same lane below
+#pragma unroll
+            for (int o = 0; o < 8; o++) cnt[o] += (unsigned)__popcll(__ballot(oct == (unsigned)o));
+        }
     }
     if (lane < 8) {
         unsigned c = 0;
@@ -123,7 +139,7 @@ __global__ __launch_bounds__(kBlock) void octant_order_kernel(const mr_ray *rays
 #pragma unroll
         for (int o = 0; o < 8; o++) {
             unsigned before = 0, total = 0;
-            for (int w = 0; w < kBlock / 64; w++) { const unsigned c = s_cnt[w][o]; total += c; if (w < wave) before += c; }
+            for (int w = 0; w < waves; w++) { const unsigned c = s_cnt[w][o]; total += c; if (w < wave) before += c; }
             off[o] = run + before;
             run += total;
         }
@@ -446,12 +462,14 @@ static mr_status launch_product(const TraceParams &p, hipStream_t stream) {
 }
 #endif
 
-mr_status launch_octant_order(const mr_ray *d_rays, unsigned long long n, uint32_t chunk_log2, uint32_t *d_order, hipStream_t stream) {
+mr_status launch_octant_order(const mr_ray *d_rays, const uint8_t *d_octants, unsigned long long n, uint32_t chunk_log2, uint32_t *d_order, hipStream_t stream) {
     if (n == 0) return MR_OK;
     if (chunk_log2 < 8 || chunk_log2 > (uint32_t)kOrderMaxChunkLog2) return fail(MR_ERR_INVALID, "ray order: chunks of 2^8 ... 2^%d rays", kOrderMaxChunkLog2);
     if (n > 0xFFFFFFFFull) return fail(MR_ERR_INVALID, "ray order: at most 2^32 - 1 rays per batch (32-bit indices)");
     const unsigned long long chunks = (n + (1ull << chunk_log2) - 1) >> chunk_log2;
-    hipLaunchKernelGGL(octant_order_kernel, dim3((unsigned)chunks), dim3(kBlock), 0, stream, d_rays, n, chunk_log2, d_order);
+    const unsigned waves = (1u << chunk_log2) / 64u < (unsigned)kOrderWaves ? (1u << chunk_log2) / 64u : (unsigned)kOrderWaves;
+    if (d_octants) hipLaunchKernelGGL(octant_order_kernel<true>, dim3((unsigned)chunks), dim3(64u * waves), 0, stream, d_rays, d_octants, n, chunk_log2, d_order);
+    else hipLaunchKernelGGL(octant_order_kernel<false>, dim3((unsigned)chunks), dim3(64u * waves), 0, stream, d_rays, d_octants, n, chunk_log2, d_order);
     MR_HIP_CHECK(hipGetLastError());
     return MR_OK;
 }

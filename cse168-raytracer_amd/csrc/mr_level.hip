@@ -72,7 +72,10 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(CHI
     for (unsigned long long k = (unsigned long long)xcd_block_id() * kTraceBlock + tid; k < n_round; k += stride) {
         const bool live = k < n;
         float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(1.f, 1.f, 1.f, -1.f);
-        if (live) { ra = reinterpret_cast<const float4 *>(a.tp.rays)[2 * k]; rb = reinterpret_cast<const float4 *>(a.tp.rays)[2 * k + 1]; }
+        if (live) {                                      // level->d_order: lane k works on ray d_order[k] of the queue
+            const unsigned long long s0 = a.tp.order ? (unsigned long long)a.tp.order[k] : k;
+            ra = reinterpret_cast<const float4 *>(a.tp.rays)[2 * s0]; rb = reinterpret_cast<const float4 *>(a.tp.rays)[2 * s0 + 1];
+        }
         // ---- the ray (Scene.cpp:278)
         mr_hit h;
         {
@@ -106,11 +109,14 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(CHI
             const mr_hit hs = make_hit<kObj>(a.tp, L, plane_hit, sb.w);
             sh = *reinterpret_cast<const float4 *>(&hs);
         }
+        asm volatile("" ::: "memory");                   // the index is read again rather than kept in registers across the traversals
+        unsigned long long src = k;
+        if (live && a.tp.order) src = a.tp.order[k];
         uint32_t pix = 0xFFFFFFFFu;
         float w0[3] = {1.f, 1.f, 1.f}, v[3] = {0.f, 0.f, 0.f};
-        if (live) pix = a.pixels ? a.pixels[k] : (uint32_t)(k / a.spp);
+        if (live) pix = a.pixels ? a.pixels[src] : (uint32_t)(src / a.spp);
         if (hit) {
-            if (a.weights) { w0[0] = a.weights[3 * k]; w0[1] = a.weights[3 * k + 1]; w0[2] = a.weights[3 * k + 2]; }
+            if (a.weights) { w0[0] = a.weights[3 * src]; w0[1] = a.weights[3 * src + 1]; w0[2] = a.weights[3 * src + 2]; }
             float out[3];
             phong_combine(diffuse, highlight, light_scale_of(a.m, sa, sb, sh), out);
             for (int c = 0; c < 3; c++) v[c] = out[c] * w0[c] * a.inv_spp;
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(CHI
                     g.d[0] = rb.x; g.d[1] = rb.y; g.d[2] = rb.z;
                     g.w0[0] = w0[0]; g.w0[1] = w0[1]; g.w0[2] = w0[2];
                     if (kPath) {
-                        id = a.ids ? a.ids[k] : (uint32_t)k;
+                        id = a.ids ? a.ids[src] : (uint32_t)src;
                         g.hray = pcg32(a.hbase ^ id) + a.bounce * 4u;
                     }
                     g.plan(refl, refr, diff, emit);
@@ -194,7 +200,7 @@ mr_status launch_level(const DeviceScene &ds, const mr_level_desc &ld, const mr_
     p.stack_depth = (int32_t)ds.stack_depth;
     p.rays = d_rays; p.hits = nullptr; p.n = n; p.n_dev = nullptr; p.stats = nullptr;
     p.planes = ds.planes; p.n_planes = ds.n_planes; p.n_spheres = ds.n_spheres;
-    p.work_counter = nullptr; p.order = nullptr;
+    p.work_counter = nullptr; p.order = ld.d_order;
     a.m = mesh_of(ds);
     for (int c = 0; c < 3; c++) { a.lt.L[c] = ld.light.position[c]; a.lt.color[c] = ld.light.color[c]; }
     a.lt.wattage = ld.light.wattage;
@@ -203,6 +209,7 @@ mr_status launch_level(const DeviceScene &ds, const mr_level_desc &ld, const mr_
     a.rgb = d_rgb;
     a.out.rays = d_out_rays; a.out.weights = d_out_weights; a.out.pixels = d_out_pixels; a.out.ids = d_out_ids; a.out.count = d_out_count;
     a.out.capacity = ((unsigned long long)ld.out_capacity_hi << 32) | ld.out_capacity_lo;
+    a.out.octants = ld.d_out_octants;
     a.counts = d_counts;
 
     const bool product = ld.flags & MR_MATH_PRODUCT, vote = ld.flags & MR_TRACE_INCOHERENT;

@@ -310,7 +310,11 @@ struct ChildQueue {
     uint32_t *pixels, *ids;       // ids may be NULL
     unsigned long long *count;
     unsigned long long capacity;  // rays the arrays have room for: a child whose slot lies beyond is counted, not stored
+    uint8_t *octants;             // may be NULL: per child, the sign bits of its direction (x | y << 1 | z << 2) for mr_order_by_octant
 };
+__device__ __forceinline__ uint8_t octant_of(const float dir[3]) {
+    return (uint8_t)((dir[0] < 0.0f ? 1u : 0u) | (dir[1] < 0.0f ? 2u : 0u) | (dir[2] < 0.0f ? 4u : 0u));
+}
 
 // wave64 compaction: one ballot per child kind; the workgroup's waves share one atomic.  Called by all threads of the
 // workgroup (lanes without a ray bring emit[] = false); a lane's children are built one at a time, straight into their
@@ -336,6 +340,7 @@ __device__ __forceinline__ void write_children(const ChildQueue &q, const ChildG
             q.weights[3 * s] = wgt[0]; q.weights[3 * s + 1] = wgt[1]; q.weights[3 * s + 2] = wgt[2];
             q.pixels[s] = pix;
             if (q.ids) q.ids[s] = child_id(id, j);
+            if (q.octants) q.octants[s] = octant_of(dir);
         }
         before += cn[j];
     }
@@ -357,6 +362,7 @@ __device__ __forceinline__ void write_children_at(const ChildQueue &q, const Chi
                 q.weights[3 * s] = wgt[0]; q.weights[3 * s + 1] = wgt[1]; q.weights[3 * s + 2] = wgt[2];
                 q.pixels[s] = pix;
                 if (q.ids) q.ids[s] = child_id(id, j);
+                if (q.octants) q.octants[s] = octant_of(dir);
             }
             s++;
         }

@@ -8,7 +8,7 @@ is missing it raises, and on a machine without a GPU every device call returns M
 """
 from .binding import (  # noqa: F401
     HIT_DTYPE, RAY_DTYPE, MISS, MiroError, Scene, PhotonMap, lib, lib_path, load_library,
-    MR_TRACE_CLOSEST, MR_TRACE_ANY, MR_RAYS_ON_DEVICE, MR_HITS_ON_DEVICE, MR_MATH_FAST, MR_COUNT_STATS, MR_TRACE_PERSISTENT, MR_MATH_PRODUCT, MR_TRACE_INCOHERENT, MR_FRAME_NO_SHADOWS,
+    MR_TRACE_CLOSEST, MR_TRACE_ANY, MR_RAYS_ON_DEVICE, MR_HITS_ON_DEVICE, MR_MATH_FAST, MR_COUNT_STATS, MR_TRACE_PERSISTENT, MR_MATH_PRODUCT, MR_TRACE_INCOHERENT, MR_FRAME_NO_SHADOWS, MR_ORDER_GIVEN,
     EXPORTED_SYMBOLS, PinnedArray, tile_pixel_map, band_locate, band_rows_of,
 )
 from . import scenes  # noqa: F401

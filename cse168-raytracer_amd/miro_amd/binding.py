@@ -24,6 +24,7 @@ MR_TRACE_PERSISTENT = 1 << 5
 MR_MATH_PRODUCT = 1 << 6
 MR_TRACE_INCOHERENT = 1 << 7
 MR_FRAME_NO_SHADOWS = 1 << 8
+MR_ORDER_GIVEN = 0x80000000
 
 MR_PATH_MIRROR, MR_PATH_REFRACT, MR_PATH_DIFFUSE = 1, 2, 4
 MR_LEVEL_LAST, MR_LEVEL_SPECULAR, MR_LEVEL_PATH = 0, 1, 2
@@ -36,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "mr_scene_create", "mr_scene_destroy", "mr_scene_add_mesh", "mr_scene_add_obj", "mr_scene_add_triangle",
     "mr_scene_add_sphere", "mr_scene_add_plane",
     "mr_bvh_build", "mr_scene_get_info", "mr_scene_get_mesh", "mr_scene_export_tree",
-    "mr_trace", "mr_host_alloc", "mr_host_free", "mr_trace_indirect", "mr_trace_grouped", "mr_trace_get_stats", "mr_gen_eye_rays", "mr_gen_eye_rays_tiled", "mr_tile_pixel_map", "mr_untile_pixels", "mr_gen_shadow_rays", "mr_hit_attrs",
+    "mr_trace", "mr_host_alloc", "mr_host_free", "mr_trace_indirect", "mr_trace_grouped", "mr_order_by_octant", "mr_trace_get_stats", "mr_gen_eye_rays", "mr_gen_eye_rays_tiled", "mr_tile_pixel_map", "mr_untile_pixels", "mr_gen_shadow_rays", "mr_hit_attrs",
     "mr_shade_direct", "mr_render_direct", "mr_band_locate", "mr_band_rows_of", "mr_deinterleave_bands", "mr_gen_path_rays", "mr_trace_level", "mr_tonemap",
     "mr_scene_set_materials", "mr_shade_accumulate", "mr_gen_secondary_rays",
     "mr_photon_map_create", "mr_photon_map_destroy", "mr_photon_map_store", "mr_photon_map_scale",
@@ -93,7 +94,8 @@ class LevelDesc(C.Structure):
     """mr_level_desc (miro_hip.h): one level of traceScene's recursion for mr_trace_level"""
     _fields_ = [("light", Light), ("spp", C.c_uint32), ("flags", C.c_uint32), ("children", C.c_uint32),
                 ("path_kinds", C.c_uint32), ("seed", C.c_uint32), ("bounce", C.c_uint32),
-                ("out_capacity_lo", C.c_uint32), ("out_capacity_hi", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+                ("out_capacity_lo", C.c_uint32), ("out_capacity_hi", C.c_uint32), ("reserved", C.c_uint32),
+                ("d_out_octants", C.c_void_p), ("d_order", C.c_void_p)]
 
 
 class Material(C.Structure):
@@ -144,7 +146,8 @@ def load_library(path=None):
     L.mr_scene_export_tree.argtypes = [vp, f32p, C.POINTER(C.c_int32), u32p]
     L.mr_trace.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp]
     L.mr_trace_indirect.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_uint32, vp]
-    L.mr_trace_grouped.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint32, C.c_uint32, vp]
+    L.mr_trace_grouped.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint32, C.c_uint32, vp]
+    L.mr_order_by_octant.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp]
     L.mr_host_alloc.argtypes = [C.POINTER(vp), C.c_uint64]
     L.mr_host_free.argtypes = [vp]
     L.mr_trace_get_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]
@@ -165,8 +168,8 @@ def load_library(path=None):
     L.mr_tonemap.argtypes = [vp, vp, C.c_uint64, vp, vp]
     L.mr_scene_set_materials.argtypes = [vp, C.POINTER(Material), C.c_uint32, u32p]
     L.mr_shade_accumulate.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, C.POINTER(Light), C.c_uint32, vp, vp]
-    L.mr_gen_secondary_rays.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp, C.c_uint64, vp]
-    L.mr_gen_path_rays.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, C.c_uint64, vp]
+    L.mr_gen_secondary_rays.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp, C.c_uint64, vp, vp]
+    L.mr_gen_path_rays.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, C.c_uint64, vp, vp]
     L.mr_trace_level.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp, vp]
     L.mr_final_gather.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_float, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.mr_photon_map_create.argtypes = [C.c_int32, C.c_uint32, C.POINTER(vp)]
@@ -379,11 +382,18 @@ class Scene:
         _check(self.L.mr_trace_indirect(self.h, d_rays.data_ptr(), d_count.data_ptr(), max_rays, d_hits.data_ptr(),
                                         flags, _stream_ptr(stream)))
 
-    def trace_grouped(self, d_rays, n, d_hits, d_order, flags=0, chunk_log2=0, stream=None):
+    def trace_grouped(self, d_rays, n, d_hits, d_order, flags=0, chunk_log2=0, stream=None, d_octants=None):
         """mr_trace_grouped: a bounce queue traced with its rays grouped by direction octant inside chunks of 2^chunk_log2
-        (d_order: int32 / uint32 tensor of n entries, written by the call); the hit buffer is mr_trace's."""
-        _check(self.L.mr_trace_grouped(self.h, d_rays.data_ptr(), n, d_hits.data_ptr(), d_order.data_ptr(), chunk_log2, flags,
-                                       _stream_ptr(stream)))
+        (d_order: int32 / uint32 tensor of n entries, written by the call unless chunk_log2 holds MR_ORDER_GIVEN); the hit
+        buffer is mr_trace's.  d_octants: the generator's octant bytes (uint8 per ray), cheaper to order from than the rays."""
+        _check(self.L.mr_trace_grouped(self.h, d_rays.data_ptr(), d_octants.data_ptr() if d_octants is not None else None, n,
+                                       d_hits.data_ptr(), d_order.data_ptr(), chunk_log2, flags, _stream_ptr(stream)))
+
+    def order_by_octant(self, d_rays, n, d_order, chunk_log2=0, stream=None, d_octants=None):
+        """mr_order_by_octant: the ray order alone (for trace_level(d_order=...) or trace_grouped(chunk_log2 | MR_ORDER_GIVEN))"""
+        _check(self.L.mr_order_by_octant(self.h, d_rays.data_ptr() if d_rays is not None else None,
+                                         d_octants.data_ptr() if d_octants is not None else None, n, chunk_log2,
+                                         d_order.data_ptr(), _stream_ptr(stream)))
 
     def stats(self, reset=True):
         a, b = C.c_uint64(0), C.c_uint64(0)
@@ -427,7 +437,7 @@ class Scene:
 
     def gen_path_rays(self, d_rays, d_hits, d_weights, d_pixels, d_ids, n, d_out_rays, d_out_weights, d_out_pixels, d_out_ids,
                       d_count, spp=1, seed=168, bounce=0, kinds=MR_PATH_MIRROR | MR_PATH_REFRACT | MR_PATH_DIFFUSE, stream=None,
-                      out_capacity=None):
+                      out_capacity=None, d_out_octants=None):
         """mr_gen_path_rays: the PATH_TRACING generators (Ray.h:124-158,235-239): up to 4 children per hit.
         out_capacity: rays the output tensors hold (default: the shortest of them)"""
         def ptr(t):
@@ -436,11 +446,13 @@ class Scene:
             out_capacity = min(t.shape[0] for t in (d_out_rays, d_out_weights, d_out_pixels, d_out_ids) if t is not None)
         _check(self.L.mr_gen_path_rays(self.h, d_rays.data_ptr(), d_hits.data_ptr(), ptr(d_weights), ptr(d_pixels), ptr(d_ids),
                                        n, spp, seed, bounce, kinds, d_out_rays.data_ptr(), d_out_weights.data_ptr(),
-                                       d_out_pixels.data_ptr(), ptr(d_out_ids), d_count.data_ptr(), out_capacity, _stream_ptr(stream)))
+                                       d_out_pixels.data_ptr(), ptr(d_out_ids), d_count.data_ptr(), out_capacity, ptr(d_out_octants),
+                                       _stream_ptr(stream)))
 
     def trace_level(self, d_rays, d_weights, d_pixels, d_ids, n, d_rgb, light_pos, wattage, children=MR_LEVEL_LAST, d_out_rays=None,
                     d_out_weights=None, d_out_pixels=None, d_out_ids=None, d_out_count=None, d_counts=None, spp=1, flags=0,
-                    seed=168, bounce=0, kinds=MR_PATH_MIRROR | MR_PATH_REFRACT, color=(1.0, 1.0, 1.0), stream=None, out_capacity=None):
+                    seed=168, bounce=0, kinds=MR_PATH_MIRROR | MR_PATH_REFRACT, color=(1.0, 1.0, 1.0), stream=None, out_capacity=None,
+                    d_out_octants=None, d_order=None):
         """mr_trace_level: trace -> shadow ray -> trace -> Phong::shade x weight -> pixel, and the next level's queue, in
         one launch (Scene.cpp:270-346)"""
         def ptr(t):
@@ -454,6 +466,7 @@ class Scene:
             outs = [t for t in (d_out_rays, d_out_weights, d_out_pixels, d_out_ids) if t is not None]
             out_capacity = min(t.shape[0] for t in outs) if outs else 0
         ld.out_capacity_lo, ld.out_capacity_hi = out_capacity & 0xFFFFFFFF, out_capacity >> 32
+        ld.d_out_octants, ld.d_order = ptr(d_out_octants), ptr(d_order)
         _check(self.L.mr_trace_level(self.h, C.byref(ld), d_rays.data_ptr(), ptr(d_weights), ptr(d_pixels), ptr(d_ids), n,
                                      d_rgb.data_ptr(), ptr(d_out_rays), ptr(d_out_weights), ptr(d_out_pixels), ptr(d_out_ids),
                                      ptr(d_out_count), ptr(d_counts), _stream_ptr(stream)))
@@ -517,14 +530,15 @@ class Scene:
                                           d_shadow_count.data_ptr(), C.byref(lt), spp, d_rgb.data_ptr(), _stream_ptr(stream)))
 
     def gen_secondary_rays(self, d_rays, d_hits, d_weights, d_pixels, n, d_out_rays, d_out_weights, d_out_pixels, d_count,
-                           spp=1, stream=None, out_capacity=None):
+                           spp=1, stream=None, out_capacity=None, d_out_octants=None):
         if out_capacity is None:
             out_capacity = min(t.shape[0] for t in (d_out_rays, d_out_weights, d_out_pixels))
         _check(self.L.mr_gen_secondary_rays(self.h, d_rays.data_ptr(), d_hits.data_ptr(),
                                             d_weights.data_ptr() if d_weights is not None else None,
                                             d_pixels.data_ptr() if d_pixels is not None else None, n, spp,
                                             d_out_rays.data_ptr(), d_out_weights.data_ptr(), d_out_pixels.data_ptr(),
-                                            d_count.data_ptr(), out_capacity, _stream_ptr(stream)))
+                                            d_count.data_ptr(), out_capacity,
+                                            d_out_octants.data_ptr() if d_out_octants is not None else None, _stream_ptr(stream)))
 
     def tonemap(self, d_rgb, n_values, d_out, stream=None):
         _check(self.L.mr_tonemap(self.h, d_rgb.data_ptr(), n_values, d_out.data_ptr(), _stream_ptr(stream)))

@@ -290,7 +290,8 @@ class FrameRenderer:
             self.step(torch.cuda.current_stream(self.device), any_hit)
         return g
 
-    def render_specular(self, depth=10, stream=None, path_tracing=False, path_seed=168, path_kinds=None, fused=False):
+    def render_specular(self, depth=10, stream=None, path_tracing=False, path_seed=168, path_kinds=None, fused=False,
+                        group_octants=True):
         """Scene::traceScene with reflective / refractive materials (Scene.cpp:270-346) as wavefront bounces: every
         level traces its queue, shades it (weight x Phong::shade added to the ray's pixel), and emits the reflect /
         Fresnel / refract children of the next level by ballot compaction.  depth = TRACE_DEPTH (Miro.h:13): rays are
@@ -301,7 +302,10 @@ class FrameRenderer:
         fused: every level is ONE launch of mr_trace_level (trace, shadow ray, trace, shade, children) instead of the seven
         of the batched calls -- the same rays and children; no hit or shadow-ray buffer exists.  fused="auto": the first
         level in one launch, a later level only if at least 90 % of the previous level's rays hit something (the one-launch
-        form runs its second traversal and its generators at the hit rate of the queue, profiles/r02_level_probe.log)."""
+        form runs its second traversal and its generators at the hit rate of the queue, profiles/r02_level_probe.log).
+        group_octants: the generators also write one octant byte per child, and every level after the first works on its
+        queue through mr_order_by_octant's index (rays grouped by direction octant inside chunks of 16 384; the same hits and
+        children, profiles/r03_octant_order.log)."""
         sc, L, W = self.scene, self.desc["light"], self.desc["wattage"]
         # this driver mixes library launches (on `stream`) with torch ops and .item() read-backs: they only order against
         # each other on torch's current stream, so `stream` must be that stream (or a torch Stream, made current here)
@@ -309,12 +313,13 @@ class FrameRenderer:
             raise TypeError("render_specular: pass a torch.cuda.Stream (or None for the current stream), not a raw handle")
         if stream is not None and stream != torch.cuda.current_stream(self.device):
             with torch.cuda.stream(stream):
-                return self.render_specular(depth, stream, path_tracing, path_seed, path_kinds, fused)
+                return self.render_specular(depth, stream, path_tracing, path_seed, path_kinds, fused, group_octants)
         self.d_slots.zero_()
         if path_kinds is None:
             path_kinds = binding.MR_PATH_MIRROR | binding.MR_PATH_REFRACT
         fan = 4 if path_tracing else 3                  # children per ray, at most
         ids = None
+        octs = None                                     # octant bytes of the current queue (None: the eye rays, in image order)
         rays, weights, pixels, n = self.d_rays, None, None, self.n
         per_level = []
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -323,26 +328,33 @@ class FrameRenderer:
                 break
             if fused is True or (fused == "auto" and (level == 0 or per_level[-1][1] >= 0.9 * per_level[-1][0])):
                 last = level == depth
-                fl = (self.flags & binding.MR_MATH_PRODUCT) | (binding.MR_TRACE_INCOHERENT if level > 0 else 0)
+                order = None
+                if octs is not None:                    # grouped waves share a direction sign: the default control flow
+                    order = torch.empty(n, dtype=torch.int32, device=self.device)
+                    sc.order_by_octant(rays, n, order, d_octants=octs, stream=stream)
+                fl = (self.flags & binding.MR_MATH_PRODUCT) | (binding.MR_TRACE_INCOHERENT if level > 0 and order is None else 0)
                 cnts = torch.zeros(3, dtype=torch.int64, device=self.device)        # rays, shadow rays, children
-                out_rays = out_w = out_pix = out_ids = None
+                out_rays = out_w = out_pix = out_ids = out_oct = None
                 if not last:
                     out_rays = torch.empty((fan * n, 8), **f32)
                     out_w = torch.empty((fan * n, 3), **f32)
                     out_pix = torch.empty(fan * n, dtype=torch.int32, device=self.device)
                     if path_tracing:
                         out_ids = torch.empty(fan * n, dtype=torch.int32, device=self.device)
+                    if group_octants:
+                        out_oct = torch.empty(fan * n, dtype=torch.uint8, device=self.device)
                 children = binding.MR_LEVEL_LAST if last else (binding.MR_LEVEL_PATH if path_tracing else binding.MR_LEVEL_SPECULAR)
                 sc.trace_level(rays, weights, pixels, ids, n, self.d_slots, L, W, children=children, d_out_rays=out_rays,
                                d_out_weights=out_w, d_out_pixels=out_pix, d_out_ids=out_ids,
                                d_out_count=None if last else cnts[2:], d_counts=cnts[:2], spp=self.spp, flags=fl, seed=path_seed,
-                               bounce=level, kinds=path_kinds, stream=stream)
+                               bounce=level, kinds=path_kinds, stream=stream, d_out_octants=out_oct, d_order=order)
                 host = cnts.tolist()
                 per_level.append((n, host[1]))
                 if last:
                     break
                 n = host[2]
                 rays, weights, pixels = out_rays[:n], out_w[:n], out_pix[:n]
+                octs = out_oct[:n] if out_oct is not None else None
                 if path_tracing:
                     ids = out_ids[:n]
                 continue
@@ -354,7 +366,11 @@ class FrameRenderer:
             # bounce queues are compacted in wave order, not in image order: from the first bounce on the batches carry the
             # MR_TRACE_INCOHERENT hint (voting control flow; the same hit records)
             fl = self.flags | (binding.MR_TRACE_INCOHERENT if level > 0 else 0)
-            sc.trace_device(rays, n, hits, fl, stream=stream)
+            if octs is not None:
+                order = torch.empty(n, dtype=torch.int32, device=self.device)
+                sc.trace_grouped(rays, n, hits, order, self.flags & binding.MR_MATH_PRODUCT, d_octants=octs, stream=stream)
+            else:
+                sc.trace_device(rays, n, hits, fl, stream=stream)
             sc.gen_shadow_rays(rays, hits, n, L, sh_rays, src, cnt, stream=stream)
             sc.trace_indirect(sh_rays, cnt, n, sh_hits, fl, stream=stream)               # closest hit: the occluder matters
             sc.shade_accumulate(rays, hits, weights, pixels, n, sh_rays, sh_hits, src, cnt, L, W, self.d_slots,
@@ -367,14 +383,17 @@ class FrameRenderer:
             out_w = torch.empty((fan * n, 3), **f32)
             out_pix = torch.empty(fan * n, dtype=torch.int32, device=self.device)
             cnt2 = torch.zeros(1, dtype=torch.int64, device=self.device)
+            out_oct = torch.empty(fan * n, dtype=torch.uint8, device=self.device) if group_octants else None
             if path_tracing:
                 out_ids = torch.empty(fan * n, dtype=torch.int32, device=self.device)
                 sc.gen_path_rays(rays, hits, weights, pixels, ids, n, out_rays, out_w, out_pix, out_ids, cnt2, spp=self.spp,
-                                 seed=path_seed, bounce=level, kinds=path_kinds, stream=stream)
+                                 seed=path_seed, bounce=level, kinds=path_kinds, stream=stream, d_out_octants=out_oct)
             else:
-                sc.gen_secondary_rays(rays, hits, weights, pixels, n, out_rays, out_w, out_pix, cnt2, spp=self.spp, stream=stream)
+                sc.gen_secondary_rays(rays, hits, weights, pixels, n, out_rays, out_w, out_pix, cnt2, spp=self.spp, stream=stream,
+                                      d_out_octants=out_oct)
             n = int(cnt2.item())
             rays, weights, pixels = out_rays[:n], out_w[:n], out_pix[:n]
+            octs = out_oct[:n] if out_oct is not None else None
             if path_tracing:
                 ids = out_ids[:n]
         self._untile(stream)

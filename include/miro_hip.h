@@ -190,9 +190,19 @@ mr_status mr_trace_indirect(mr_scene *scene, const mr_ray *d_rays, const uint64_
  * d_hits[d_order[k]]: the hit buffer is byte for byte that of mr_trace on the same rays; whole waves share a direction
  * sign (the octant-specialised loops apply) and rays that leave the scene at once stop holding waves.  Measured on the
  * stand-in atrium's diffuse-bounce queue: 5.2 -> 6.0 Grays/s; on the bunny's: 22 -> 31 (profiles/r03_octant_order.log).
- * flags: MR_TRACE_ANY, MR_MATH_PRODUCT, MR_TRACE_INCOHERENT. */
-mr_status mr_trace_grouped(mr_scene *scene, const mr_ray *d_rays, uint64_t n, mr_hit *d_hits, uint32_t *d_order,
-                           uint32_t chunk_log2, uint32_t flags, void *stream);
+ * flags: MR_TRACE_ANY, MR_MATH_PRODUCT, MR_TRACE_INCOHERENT.
+ * d_octants (may be NULL): one byte per ray holding the sign bits of its direction (x<0 | y<0 << 1 | z<0 << 2), as the
+ * generators write them (d_out_octants of mr_gen_secondary_rays / mr_gen_path_rays / mr_level_desc); the order is then made
+ * from 1 byte per ray instead of the 32-byte rays -- the order kernel is bandwidth-bound, this is what it costs.  The bytes are
+ * trusted to be the rays' octants: other values change the grouping, never the hit buffer.
+ * chunk_log2 | MR_ORDER_GIVEN: d_order is an INPUT -- a permutation of 0 ... n-1 the caller made (mr_order_by_octant, or the
+ * one an earlier call on the same rays left there); it is not checked, an index >= n reads and writes out of bounds.
+ * mr_order_by_octant is the first half alone (d_rays may be NULL when d_octants is given): for mr_level_desc.d_order. */
+#define MR_ORDER_GIVEN 0x80000000u
+mr_status mr_order_by_octant(mr_scene *scene, const mr_ray *d_rays, const uint8_t *d_octants, uint64_t n, uint32_t chunk_log2,
+                             uint32_t *d_order, void *stream);
+mr_status mr_trace_grouped(mr_scene *scene, const mr_ray *d_rays, const uint8_t *d_octants, uint64_t n, mr_hit *d_hits,
+                           uint32_t *d_order, uint32_t chunk_log2, uint32_t flags, void *stream);
 /* -DSTATS counters accumulated by MR_COUNT_STATS traces (synchronises the device) */
 mr_status mr_trace_get_stats(mr_scene *scene, uint64_t *box_tests, uint64_t *tri_tests, int32_t reset);
 
@@ -310,10 +320,12 @@ mr_status mr_shade_accumulate(mr_scene *scene, const mr_ray *d_rays, const mr_hi
  * material: up to three children per ray (room for 3n), compacted by wave64 ballot + prefix sum, each with its path
  * weight and pixel.  d_count: device uint64 receiving the number of children (zeroed by the call).
  * out_capacity: rays the output arrays have room for.  Children beyond it are counted but not stored: *d_count >
- * out_capacity afterwards means the queue was too small (3n always suffices) -- nothing is written out of bounds. */
+ * out_capacity afterwards means the queue was too small (3n always suffices) -- nothing is written out of bounds.
+ * d_out_octants (may be NULL): one byte per child, the sign bits of its direction -- mr_trace_grouped's d_octants. */
 mr_status mr_gen_secondary_rays(mr_scene *scene, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
                                 const uint32_t *d_pixels, uint64_t n, uint32_t spp, mr_ray *d_out_rays, float *d_out_weights,
-                                uint32_t *d_out_pixels, uint64_t *d_count, uint64_t out_capacity, void *stream);
+                                uint32_t *d_out_pixels, uint64_t *d_count, uint64_t out_capacity, uint8_t *d_out_octants,
+                                void *stream);
 
 /* The PATH_TRACING build of those generators (Ray.h:149-158,235-239) plus Ray::random (Ray.h:124-140): every child is
  * drawn from a lobe (alignHemisphereToVector, Utility.h:34-50) around the mirror / refracted direction with
@@ -327,7 +339,7 @@ enum { MR_PATH_MIRROR = 1u, MR_PATH_REFRACT = 2u, MR_PATH_DIFFUSE = 4u };
 mr_status mr_gen_path_rays(mr_scene *scene, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,
                            const uint32_t *d_pixels, const uint32_t *d_ids, uint64_t n, uint32_t spp, uint32_t seed,
                            uint32_t bounce, uint32_t kinds, mr_ray *d_out_rays, float *d_out_weights, uint32_t *d_out_pixels,
-                           uint32_t *d_out_ids, uint64_t *d_count, uint64_t out_capacity, void *stream);
+                           uint32_t *d_out_ids, uint64_t *d_count, uint64_t out_capacity, uint8_t *d_out_octants, void *stream);
 
 /* ---- one level of Scene::traceScene's recursion (Scene.cpp:270-346) in ONE launch -------------------------------
  * For every ray of the queue: Scene::trace -> Phong::shade (shadow ray, Scene::trace, the occluder's light scale,
@@ -351,7 +363,9 @@ typedef struct mr_level_desc {
     uint32_t spp, flags, children;
     uint32_t path_kinds, seed, bounce;
     uint32_t out_capacity_lo, out_capacity_hi;
-    uint32_t reserved[2];
+    uint32_t reserved;
+    uint8_t *d_out_octants;       /* may be NULL: per child, the sign bits of its direction (mr_order_by_octant's input) */
+    const uint32_t *d_order;      /* may be NULL: lane k works on ray d_order[k] of the queue (a permutation of 0 ... n-1) */
 } mr_level_desc;
 mr_status mr_trace_level(mr_scene *scene, const mr_level_desc *level, const mr_ray *d_rays, const float *d_weights,
                          const uint32_t *d_pixels, const uint32_t *d_ids, uint64_t n, float *d_rgb, mr_ray *d_out_rays,

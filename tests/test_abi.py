@@ -78,7 +78,9 @@ def test_round2_entry_points_fail_loudly_without_a_device(miro):
     dummy = C.c_void_p(16)
     assert L.mr_render_direct(s.h, C.byref(fd), dummy, None, None, None, None) == -5
     assert b"CPU" in L.mr_last_error() or b"device" in L.mr_last_error()
-    assert L.mr_gen_path_rays(s.h, dummy, dummy, None, None, None, 4, 1, 1, 0, 7, dummy, dummy, dummy, None, dummy, 16, None) == -5
+    assert L.mr_gen_path_rays(s.h, dummy, dummy, None, None, None, 4, 1, 1, 0, 7, dummy, dummy, dummy, None, dummy, 16, None, None) == -5
+    assert L.mr_order_by_octant(s.h, dummy, None, 4, 0, dummy, None) == -5
+    assert L.mr_trace_grouped(s.h, dummy, None, 4, dummy, dummy, 0, 0, None) == -5
     assert L.mr_deinterleave_bands(s.h, dummy, dummy, 4, 4, 2, 2, 2, 3, None) == -5
     # pure host arithmetic works anywhere
     assert miro.band_rows_of(10, 4, 0, 2) == 6 and miro.band_rows_of(10, 4, 1, 2) == 4

@@ -268,3 +268,67 @@ def test_child_queues_are_bounded_by_out_capacity(miro):
                       d_out_weights=q[1], d_out_pixels=q[2], d_out_count=q[4], spp=spp, out_capacity=0)
     with pytest.raises(miro.MiroError):
         b.gen_secondary_rays(d_rays, d_hits, None, None, n, q[0], q[1], q[2], q[4], spp=spp, out_capacity=0)
+
+
+@pytest.mark.gpu
+def test_octant_bytes_and_ordered_levels(miro):
+    """The generators' d_out_octants are the sign bits of the children they wrote (batched generators and mr_trace_level
+    alike); mr_order_by_octant makes the same index from those bytes as from the rays; mr_trace_grouped fed with the bytes
+    returns mr_trace's hit buffer; and a level worked through that index (mr_level_desc.d_order) emits the same children --
+    compared as sets by ray id -- and the same pixel sums up to the order of the float atomics."""
+    import torch
+    name, W, H, spp = "bunny", 160, 120, 4
+    b = product_scene(miro, name)
+    d = scenes.SCENES[name]
+    n = W * H * spp
+    i32 = dict(dtype=torch.int32, device="cuda")
+    d_rays = torch.empty((n, 8), dtype=torch.float32, device="cuda")
+    d_hits = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    b.gen_eye_rays(binding.make_camera(d["eye"], d["lookat"], d["up"], d["fov"]), W, H, d_rays, spp=spp, jitter=True)
+    b.trace_device(d_rays, n, d_hits)
+
+    def queue():
+        return dict(rays=torch.zeros((n, 8), dtype=torch.float32, device="cuda"), w=torch.zeros((n, 3), dtype=torch.float32, device="cuda"),
+                    pix=torch.zeros(n, **i32), ids=torch.zeros(n, **i32), oct=torch.full((n,), 255, dtype=torch.uint8, device="cuda"),
+                    cnt=torch.zeros(1, dtype=torch.int64, device="cuda"))
+
+    def signs(q, m):
+        r = q["rays"][:m]
+        return ((r[:, 4] < 0).to(torch.uint8) | ((r[:, 5] < 0).to(torch.uint8) << 1) | ((r[:, 6] < 0).to(torch.uint8) << 2))
+
+    # ---- batched generator
+    q = queue()
+    b.gen_path_rays(d_rays, d_hits, None, None, None, n, q["rays"], q["w"], q["pix"], q["ids"], q["cnt"], spp=spp, seed=5,
+                    kinds=binding.MR_PATH_DIFFUSE, d_out_octants=q["oct"])
+    m = int(q["cnt"].item())
+    assert m > 20000 and torch.equal(q["oct"][:m], signs(q, m)) and bool((q["oct"][m:] == 255).all())
+    assert len(torch.unique(q["oct"][:m])) == 8
+    # ---- the index from the bytes is the index from the rays
+    o_rays, o_bytes = torch.full((m,), -1, **i32), torch.full((m,), -2, **i32)
+    for lg in (8, 12, 0):
+        b.order_by_octant(q["rays"], m, o_rays, chunk_log2=lg)
+        b.order_by_octant(None, m, o_bytes, chunk_log2=lg, d_octants=q["oct"])
+        assert torch.equal(o_rays, o_bytes)
+    hits_a = torch.empty((m, 4), dtype=torch.float32, device="cuda")
+    hits_b = torch.full((m, 4), 3.0, dtype=torch.float32, device="cuda")
+    b.trace_device(q["rays"], m, hits_a)
+    b.trace_grouped(q["rays"], m, hits_b, o_bytes, d_octants=q["oct"])
+    assert torch.equal(hits_a.view(torch.int32), hits_b.view(torch.int32))
+    # ---- one level of the bounce queue, as made and through the index
+    res = []
+    for order in (None, o_bytes):
+        q2 = queue()
+        rgb = torch.zeros((W * H, 3), dtype=torch.float32, device="cuda")
+        b.trace_level(q["rays"][:m], q["w"][:m], q["pix"][:m], q["ids"][:m], m, rgb, d["light"], d["wattage"],
+                      children=binding.MR_LEVEL_PATH, d_out_rays=q2["rays"], d_out_weights=q2["w"], d_out_pixels=q2["pix"],
+                      d_out_ids=q2["ids"], d_out_count=q2["cnt"], spp=spp, seed=5, bounce=1, kinds=binding.MR_PATH_DIFFUSE,
+                      d_out_octants=q2["oct"], d_order=order)
+        m2 = int(q2["cnt"].item())
+        assert torch.equal(q2["oct"][:m2], signs(q2, m2))
+        by_id = torch.argsort(((q2["ids"][:m2].to(torch.int64) & 0xFFFFFFFF) << 32) | (q2["rays"][:m2, 0].contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF))
+        res.append((m2, q2["ids"][:m2][by_id], q2["rays"][:m2][by_id], q2["w"][:m2][by_id], q2["pix"][:m2][by_id], rgb))
+    assert res[0][0] == res[1][0] > 100
+    for x, y in zip(res[0][1:5], res[1][1:5]):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    scale = float(res[0][5].abs().max())
+    assert scale > 0 and float((res[0][5] - res[1][5]).abs().max()) <= 1e-5 * scale

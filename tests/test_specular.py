@@ -50,9 +50,11 @@ def build_both(oracle, miro):
     return a, b, clamp_like_phong_ctor(mats), prim_mat
 
 
+@pytest.mark.parametrize("grouped", [True, False], ids=["grouped", "as-made"])
 @pytest.mark.parametrize("fused", [False, True, "auto"], ids=["batched", "fused", "auto"])
-def test_specular_frame_matches_oracle(oracle, miro, fused):
-    """fused: every level is one launch of mr_trace_level instead of the seven batched calls"""
+def test_specular_frame_matches_oracle(oracle, miro, fused, grouped):
+    """fused: every level is one launch of mr_trace_level instead of the seven batched calls; grouped: the queues of the
+    levels after the first are worked through mr_order_by_octant's index"""
     import torch
     assert torch.cuda.is_available()
     a, b, mats11, prim_mat = build_both(oracle, miro)
@@ -60,7 +62,7 @@ def test_specular_frame_matches_oracle(oracle, miro, fused):
     W, H, spp = 96, 72, 2
     fr = mframe.FrameRenderer(b, d, W, H, spp=spp)
     fr.generate()
-    levels = fr.render_specular(depth=10, fused=fused)
+    levels = fr.render_specular(depth=10, fused=fused, group_octants=grouped)
     torch.cuda.synchronize()
     rays = oracle.eye_rays(camera_of(oracle, "teapot"), W, H, spp=spp, jitter=True, seed=168)
     want_rays, calls = a.trace_scene(mats11, prim_mat, rays, d["light"], d["wattage"], depth=10)
@@ -78,9 +80,10 @@ def test_specular_frame_matches_oracle(oracle, miro, fused):
     assert scale > 0
 
 
+@pytest.mark.parametrize("grouped", [True, False], ids=["grouped", "as-made"])
 @pytest.mark.parametrize("fused", [False, True], ids=["batched", "fused"])
 @pytest.mark.parametrize("kinds,depth", [(3, 4), (7, 2)])
-def test_path_traced_frame_matches_oracle(oracle, miro, kinds, depth, fused):
+def test_path_traced_frame_matches_oracle(oracle, miro, kinds, depth, fused, grouped):
     """Scene::traceScene as the PATH_TRACING build runs it -- glossy mirror (finite shininess) and rough glass, every child
     drawn from its lobe with the counter-based generator; kinds = 7 adds the diffuse bounce of Ray::random (extension).
     Same ray totals per level as the oracle's recursion makes Scene::trace calls, pixels within the tolerance of the
@@ -96,7 +99,7 @@ def test_path_traced_frame_matches_oracle(oracle, miro, kinds, depth, fused):
     W, H, spp = 64, 48, 2
     fr = mframe.FrameRenderer(b, d, W, H, spp=spp)
     fr.generate()
-    levels = fr.render_specular(depth=depth, path_tracing=True, path_seed=99, path_kinds=kinds, fused=fused)
+    levels = fr.render_specular(depth=depth, path_tracing=True, path_seed=99, path_kinds=kinds, fused=fused, group_octants=grouped)
     torch.cuda.synchronize()
     got = fr.d_rgb.cpu().numpy()
     rays = oracle.eye_rays(camera_of(oracle, "teapot"), W, H, spp=spp, jitter=True, seed=168)

@@ -34,18 +34,25 @@ def main():
     fr.generate()
     torch.cuda.synchronize()
     res = {}
-    for fused in (False, True, "auto"):
-        levels = fr.render_specular(depth=a.depth, path_tracing=True, path_seed=5, path_kinds=a.kinds, fused=fused)   # warm-up
+    for fused, grouped in ((False, False), (False, True), (True, False), (True, True), ("auto", False), ("auto", True)):
+        kw = dict(depth=a.depth, path_tracing=True, path_seed=5, path_kinds=a.kinds, fused=fused, group_octants=grouped)
+        levels = fr.render_specular(**kw)   # warm-up
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.reps):
-            levels = fr.render_specular(depth=a.depth, path_tracing=True, path_seed=5, path_kinds=a.kinds, fused=fused)
+            levels = fr.render_specular(**kw)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / a.reps * 1e3
         rays = sum(n + s for n, s in levels)
-        res[fused] = (ms, levels, fr.d_rgb.clone())
-        print("%s %dx%dx%d depth %d kinds %d, %-8s %8.3f ms/frame  %7.2f Grays/s  levels %s" %
-              (a.scene, a.w, a.h, a.spp, a.depth, a.kinds, {False: "batched", True: "fused", "auto": "auto"}[fused], ms, rays / ms / 1e6, levels), flush=True)
+        if grouped:
+            assert levels == res[fused][1], "ray counts differ with grouped queues"
+            err = float((fr.d_rgb - res[fused][2]).abs().max())
+            print("  grouped queues: same ray counts per level; max pixel difference %.3g (float-atomic order)" % err)
+        else:
+            res[fused] = (ms, levels, fr.d_rgb.clone())
+        print("%s %dx%dx%d depth %d kinds %d, %-8s %-9s %8.3f ms/frame  %7.2f Grays/s  levels %s" %
+              (a.scene, a.w, a.h, a.spp, a.depth, a.kinds, {False: "batched", True: "fused", "auto": "auto"}[fused],
+               "grouped" if grouped else "as made", ms, rays / ms / 1e6, levels), flush=True)
     assert res[False][1] == res[True][1], "ray counts differ"
     scale = float(res[False][2].abs().max())
     err = float((res[False][2] - res[True][2]).abs().max())

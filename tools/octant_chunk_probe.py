@@ -78,4 +78,31 @@ for name, W, H, spp in (("sponza", 1920, 1080, 4), ("bunny", 1024, 1024, 16)):
             same = bool(torch.equal(out.view(torch.int32), ref.view(torch.int32)))
             print("  mr_trace_grouped 2^%-2d  %-10s %7.3f ms  %6.2f Grays/s  (%+.1f %%)  %s" % (
                 lg, fname, ms, m / ms / 1e6, 100.0 * (base[fname] / ms - 1.0), "same hit buffer" if same else "DIFFERENT HITS"))
+    # the product call with the generator's octant bytes (made here with torch: what mr_gen_path_rays' d_out_octants holds)
+    octs = ((q[:, 4] < 0).to(torch.uint8) | ((q[:, 5] < 0).to(torch.uint8) << 1) | ((q[:, 6] < 0).to(torch.uint8) << 2)).contiguous()
+    for lg in (13, 14):
+        for fname, fl in (("default", 0), ("incoherent", miro_amd.MR_TRACE_INCOHERENT)):
+            out.zero_()
+            sc.trace_grouped(q, m, out, order, fl, chunk_log2=lg, stream=st, d_octants=octs)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(5):
+                sc.trace_grouped(q, m, out, order, fl, chunk_log2=lg, stream=st, d_octants=octs)
+            e1.record(st)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            same = bool(torch.equal(out.view(torch.int32), ref.view(torch.int32)))
+            print("  grouped, octant bytes 2^%-2d  %-10s %7.3f ms  %6.2f Grays/s  (%+.1f %%)  %s" % (
+                lg, fname, ms, m / ms / 1e6, 100.0 * (base[fname] / ms - 1.0), "same hit buffer" if same else "DIFFERENT HITS"))
+    # the gathering trace alone (the order of the last call reused): what the order kernel costs is the difference
+    for fname, fl in (("default", 0), ("incoherent", miro_amd.MR_TRACE_INCOHERENT)):
+        sc.trace_grouped(q, m, out, order, fl, chunk_log2=14, stream=st)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(5):
+            sc.trace_grouped(q, m, out, order, fl, chunk_log2=14 | miro_amd.MR_ORDER_GIVEN, stream=st)
+        e1.record(st)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        print("  gather only      2^14  %-10s %7.3f ms  %6.2f Grays/s  (%+.1f %%)" % (fname, ms, m / ms / 1e6, 100.0 * (base[fname] / ms - 1.0)))
     del sc
