@@ -291,7 +291,7 @@ class FrameRenderer:
         return g
 
     def render_specular(self, depth=10, stream=None, path_tracing=False, path_seed=168, path_kinds=None, fused=False,
-                        group_octants=True):
+                        group_octants=False):
         """Scene::traceScene with reflective / refractive materials (Scene.cpp:270-346) as wavefront bounces: every
         level traces its queue, shades it (weight x Phong::shade added to the ray's pixel), and emits the reflect /
         Fresnel / refract children of the next level by ballot compaction.  depth = TRACE_DEPTH (Miro.h:13): rays are
@@ -305,7 +305,8 @@ class FrameRenderer:
         form runs its second traversal and its generators at the hit rate of the queue, profiles/r02_level_probe.log).
         group_octants: the generators also write one octant byte per child, and every level after the first works on its
         queue through mr_order_by_octant's index (rays grouped by direction octant inside chunks of 16 384; the same hits and
-        children, profiles/r03_octant_order.log)."""
+        children).  Off by default: the bounce rays' own traversal gains 9-13 %, the frame does not (the shadow rays of grouped
+        lanes are no more coherent, the pixel runs of accumulate_runs break up, profiles/r03_octant_order.log)."""
         sc, L, W = self.scene, self.desc["light"], self.desc["wattage"]
         # this driver mixes library launches (on `stream`) with torch ops and .item() read-backs: they only order against
         # each other on torch's current stream, so `stream` must be that stream (or a torch Stream, made current here)
