@@ -270,8 +270,10 @@ mr_status flatten_and_upload(mr_scene *s, uint32_t layout) {
     d.stack_depth = t.max_depth + 1;   // pending far children (one per inner node on a root-to-leaf path, <= max_depth) + the kDone sentinel
     MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&s->d_stats), 2 * sizeof(unsigned long long)));
     MR_HIP_CHECK(hipMemset(s->d_stats, 0, 2 * sizeof(unsigned long long)));
-    MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&s->d_work_counters), kWorkCounters * sizeof(unsigned long long)));
-    MR_HIP_CHECK(hipMemset(s->d_work_counters, 0, kWorkCounters * sizeof(unsigned long long)));
+    // two rings: [0, kWorkCounters) for the persistent trace kernels (zeroed before each launch), [kWorkCounters, 2 kWorkCounters) for
+    // the tails of large frames (zero here, re-armed by the launch's last reader: mr_frame.hip)
+    MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&s->d_work_counters), 2 * kWorkCounters * sizeof(unsigned long long)));
+    MR_HIP_CHECK(hipMemset(s->d_work_counters, 0, 2 * kWorkCounters * sizeof(unsigned long long)));
     return upload_materials(s);
 }
 
@@ -804,7 +806,7 @@ mr_status mr_render_direct(mr_scene *s, const mr_frame_desc *frame, float *d_rgb
     if (fd.band_world <= 1) { fd.band_world = 1; fd.band_rank = 0; if (fd.band_rows == 0) fd.band_rows = 1; }
     MR_HIP_CHECK(hipSetDevice(s->device));
     return launch_frame(s->dev, fd, d_rgb, d_hits, d_shadow_hits, reinterpret_cast<unsigned long long *>(d_counts),
-                        static_cast<hipStream_t>(stream));
+                        s->d_work_counters + kWorkCounters + (s->next_counter.fetch_add(1) % kWorkCounters), static_cast<hipStream_t>(stream));
 }
 
 mr_status mr_scene_set_materials(mr_scene *s, const mr_material *mats, uint32_t n_mats, const uint32_t *prim_material) {

@@ -37,7 +37,65 @@ struct FrameArgs {
     mr_hit *shadow_hits;         // optional: record of sample k's shadow ray (prim = MR_MISS, t = 0 when it has none)
     float *rgb;                  // [rows * W][3], window rows in band order, image order inside a row
     unsigned long long *counts;  // optional: [0] += primary rays, [1] += shadow rays traced by this launch
+    // which chunks (kTraceBlock consecutive samples) a workgroup renders: see frame_schedule()
+    uint32_t body_wgs, body_iters, tail_base, tail_chunks;      // tail_base = body_wgs * body_iters: the first tail chunk
+    unsigned *tail_counter;      // hand-out counter of the tail chunks: 0 before the launch, left at 0 by its last reader
 };
+
+// A kernel argument read where it is used, every time (volatile): the tail's parameters are needed a few dozen times per launch,
+// on a path 3 % of the workgroups take -- loaded once up front they would hold scalar registers through both traversals of
+// every workgroup (the kernel already keeps 70 of them spilled in VGPR lanes).
+template <typename T>
+__device__ __forceinline__ T kernarg_now(size_t offset) {
+    typedef const volatile T __attribute__((address_space(4))) *ptr_t;
+    const char __attribute__((address_space(4))) *ka = (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    return *(ptr_t)(ka + offset);
+}
+
+// The launch's shape.  Workgroups b < body_wgs render chunks b', b' + body_wgs, ... (body_iters of them, b' = the XCD-aware
+// permutation of b).  Frames of 2^16 chunks or more (1080p from 16 samples per pixel) keep their last tail_chunks chunks -- 6 % --
+// out of that: kTailWgs further workgroups, the last to be dealt out, one per resident slot, PULL them one at a time from a
+// counter until none is left.  Why (tools/wg_timeline.py, profiles/r03_wg_timeline.log): workgroups are dealt out in index order,
+// seven per CU, every eighth to the same XCD whatever that XCD still has to do.  With 65 536 equal workgroups (8 chunks, 0.42 ms
+// each on the bench frame) the last ones started at 97 % of the launch and the CUs drained for a whole workgroup lifetime, while
+// the XCDs -- each renders its own regions of the image -- finished between 98 and 100 %: 18 % of the slots empty from 95 to
+// 98 % of the launch, 87 % after that, 4.3 % of the launch's workgroup-slots unused in all.  Shorter workgroups throughout cost
+// more than they return (profiles/r03_grid_ab.log).  A tail that whoever is free pulls from fills the drain and evens out the
+// XCDs (slots unused: 2.0 %), and with it LONGER body workgroups pay: 32 chunks each (15 228 workgroups instead of 65 536) is
+// +0.6 % over 8.  Bench frame 16.55 -> 16.85 Grays/s, 1080p x 16 spp 14.86 -> 15.28; 4 spp and below are better off without
+// (profiles/r03_tail_ab.log).  Every chunk is rendered by exactly one workgroup either way: the picture does not change.
+#ifndef MIRO_TAIL_PERMILLE
+#define MIRO_TAIL_PERMILLE 60
+#endif
+#ifndef MIRO_BODY_ITERS
+#define MIRO_BODY_ITERS 32
+#endif
+#ifndef MIRO_TAIL_MIN_CHUNKS
+#define MIRO_TAIL_MIN_CHUNKS (1ull << 16)
+#endif
+constexpr uint32_t kTailWgs = 1792 * (256 / kTraceBlock);   // one per resident slot: 7 workgroups of 4 waves x 256 CUs
+constexpr uint32_t kBodyMinWgs = 14000;      // ~8 body workgroups per resident slot, at least
+struct FrameShape { uint32_t body_wgs, body_iters, tail_chunks, grid; };
+inline FrameShape frame_schedule(unsigned long long chunks) {
+    FrameShape s;
+    if (chunks < MIRO_TAIL_MIN_CHUNKS || MIRO_TAIL_PERMILLE == 0 || kTraceBlock != 256) {
+        const unsigned long long cap = chunks < kFrameLargeChunks ? (unsigned long long)kTraceGridCap : (unsigned long long)kFrameGridCapLarge;
+        s.body_wgs = (uint32_t)(chunks < cap ? chunks : cap);
+        s.body_iters = (uint32_t)((chunks + s.body_wgs - 1) / s.body_wgs);
+        s.tail_chunks = 0;
+        s.grid = s.body_wgs;
+        return s;
+    }
+    const unsigned long long tail_target = chunks * MIRO_TAIL_PERMILLE / 1000;
+    uint32_t m = MIRO_BODY_ITERS;
+    while (m > 1 && (chunks - tail_target) / m < kBodyMinWgs) m >>= 1;
+    while ((unsigned long long)m * (unsigned long long)kFrameGridCapLarge < chunks) m <<= 1;
+    s.body_iters = m;
+    s.body_wgs = (uint32_t)((chunks - tail_target) / m);
+    s.tail_chunks = (uint32_t)(chunks - (unsigned long long)s.body_wgs * m);
+    s.grid = s.body_wgs + kTailWgs;
+    return s;
+}
 
 // VAR: the traversal variant of trace_ray (mr_traverse.h) for both rays.
 // SHADOW: 0 = the shadow ray is a closest-hit query as Phong.cpp:97; 1 = it stops at its first accepted hit (opaque scenes:
@@ -46,12 +104,19 @@ struct FrameArgs {
 // MAT: Phong::shade with the scene's per-object materials (mr_scene_set_materials) instead of the frame's uniform one:
 // diffuse term and highlight from the hit's material (Phong.cpp:116-156) and light through a refractive occluder scaled by
 // dot(N, l) of the occluder (Phong.cpp:99-113) -- the pieces of mr_recursion.h that mr_trace_level shades with.
+#if defined(MIRO_WG_TIMES) && MIRO_TRACE_BLOCK == 256
+// measurement build only (make VARIANT=_wgt FRAME_DEFS=-DMIRO_WG_TIMES; tools/wg_timeline.py): every workgroup leaves its start and
+// end time (100 MHz constant clock), the CU it ran on and its XCD -- where the launch's idle VALU cycles sit
+__device__ unsigned long long g_wg_times[4 * 131072];
+#endif
 template <int VAR, int SHADOW, bool MAT>
 __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(7, 8))) void frame_kernel(FrameArgs a) {
+#if defined(MIRO_WG_TIMES) && MIRO_TRACE_BLOCK == 256
+    const unsigned long long wg_t0 = wall_clock64();
+#endif
     extern __shared__ int s_stack[];                  // [stack_depth][kTraceBlock]
     __shared__ unsigned s_shadow_rays[kTraceBlock / 64];
     const int tid = threadIdx.x;
-    const unsigned long long stride = (unsigned long long)gridDim.x * kTraceBlock;
     const unsigned long long n = a.eye.n, n_round = (n + 63ull) & ~63ull;
     constexpr bool kObj = (VAR & 32) != 0;
     const uint32_t spp = a.eye.spp;
@@ -59,8 +124,28 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(7, 
     Stats st = {0ull, 0ull};
     unsigned my_shadow_rays = 0;
 
-    const unsigned bid = xcd_block_id();
-    for (unsigned long long idx = (unsigned long long)bid * kTraceBlock + tid; idx < n_round; idx += stride) {
+    // body workgroups stride over their chunks as every trace kernel does; a tail workgroup (stride 0) asks the counter for its
+    // next chunk instead -- values at or beyond tail_chunks mean "none left" (each tail workgroup reads exactly one such value)
+    __shared__ unsigned s_pull;
+    unsigned long long idx, stride, limit;
+    if (blockIdx.x < a.body_wgs) {
+        const unsigned long long body_end = (unsigned long long)a.body_wgs * a.body_iters * kTraceBlock;
+        idx = (unsigned long long)xcd_block_id_of(blockIdx.x, a.body_wgs, a.body_wgs >= (unsigned)kFrameGridCapLarge || a.tail_chunks != 0, a.tail_chunks != 0 ? 4096u : kXcdMinGrid) * kTraceBlock + tid;
+        stride = (unsigned long long)a.body_wgs * kTraceBlock;
+        limit = body_end < n_round ? body_end : n_round;
+    } else {
+        idx = 0; stride = 0; limit = n_round;
+    }
+    for (;; idx += stride) {
+        if (__builtin_expect(stride == 0, 0)) {
+            if (tid == 0) s_pull = atomicAdd(kernarg_now<unsigned *>(offsetof(FrameArgs, tail_counter)), 1u);
+            __syncthreads();
+            const unsigned c = s_pull;
+            __syncthreads();
+            if (c >= kernarg_now<uint32_t>(offsetof(FrameArgs, tail_chunks))) break;   // the whole workgroup leaves together: there are barriers on this path
+            idx = ((unsigned long long)kernarg_now<uint32_t>(offsetof(FrameArgs, tail_base)) + c) * kTraceBlock + tid;
+            if (idx >= limit) continue;               // waves beyond the end of a ragged last chunk
+        } else if (idx >= limit) break;               // (whole waves: limit is a multiple of 64)
         const bool live = idx < n;
         uint32_t x = 0, row = 0, y = 0, sm = 0;
         float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(1.f, 1.f, 1.f, -1.f);
@@ -144,6 +229,11 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(7, 
         }
     }
 
+    if (stride == 0 && tid == 0) {                    // the tail's last reader re-arms the counter for the next launch
+        const unsigned readers = gridDim.x - kernarg_now<uint32_t>(offsetof(FrameArgs, body_wgs));
+        if (s_pull == kernarg_now<uint32_t>(offsetof(FrameArgs, tail_chunks)) + readers - 1u)
+            atomicExch(kernarg_now<unsigned *>(offsetof(FrameArgs, tail_counter)), 0u);
+    }
     if (a.counts) {
         // rays traced.  Shadow rays: one atomic per workgroup (a single counter word drains ~88 atomics per microsecond:
         // a 1-spp frame's 8 100 workgroups are already a measurable 4 % with two words each); primary rays: the launch's
@@ -159,19 +249,37 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(7, 
             if (blockIdx.x == 0) atomicAdd(&a.counts[0], n);
         }
     }
+#if defined(MIRO_WG_TIMES) && MIRO_TRACE_BLOCK == 256
+    if (tid == 0 && blockIdx.x < 131072u) {
+        g_wg_times[4 * blockIdx.x] = wg_t0;
+        g_wg_times[4 * blockIdx.x + 1] = wall_clock64();
+        g_wg_times[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
+        g_wg_times[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+    }
+#endif
 }
+#if defined(MIRO_WG_TIMES) && MIRO_TRACE_BLOCK == 256
+}  // namespace
+}  // namespace mr
+extern "C" int mr_debug_wg_times(unsigned long long *out, unsigned n_words) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mr::g_wg_times), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+namespace mr {
+namespace {
+#endif
 
 template <int VAR, int SHADOW, bool MAT>
-mr_status launch_frame_t(const FrameArgs &a, hipStream_t stream) {
+mr_status launch_frame_t(FrameArgs a, hipStream_t stream) {
     const size_t lds = (size_t)a.tp.stack_depth * kTraceBlock * sizeof(int);
     if (lds > 150 * 1024) return fail(MR_ERR_INVALID, "traversal stack of depth %d does not fit in LDS", a.tp.stack_depth);
     if (lds > 48 * 1024)
         MR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&frame_kernel<VAR, SHADOW, MAT>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    unsigned long long blocks = (a.eye.n + kTraceBlock - 1) / kTraceBlock;
-    const unsigned long long cap = blocks >= kFrameLargeChunks ? (unsigned long long)kFrameGridCapLarge : (unsigned long long)kTraceGridCap;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((frame_kernel<VAR, SHADOW, MAT>), dim3((unsigned)blocks), dim3(kTraceBlock), lds, stream, a);
+    const FrameShape shape = frame_schedule((a.eye.n + kTraceBlock - 1) / kTraceBlock);
+    a.body_wgs = shape.body_wgs; a.body_iters = shape.body_iters; a.tail_chunks = shape.tail_chunks;
+    a.tail_base = shape.body_wgs * shape.body_iters;
+    if (shape.tail_chunks && !a.tail_counter) return fail(MR_ERR_STATE, "mr_render_direct: no hand-out counter for the tail of a large frame");
+    hipLaunchKernelGGL((frame_kernel<VAR, SHADOW, MAT>), dim3(shape.grid), dim3(kTraceBlock), lds, stream, a);
     MR_HIP_CHECK(hipGetLastError());
     return MR_OK;
 }
@@ -198,8 +306,9 @@ mr_status launch_frame_default(const FrameArgs &a, bool any, bool no_shadows, bo
 #define MR_FRAME_ENTRY launch_frame_b256
 #endif
 mr_status MR_FRAME_ENTRY(const DeviceScene &ds, const mr_frame_desc &fd, float *d_rgb, mr_hit *d_hits, mr_hit *d_shadow_hits,
-                         unsigned long long *d_counts, hipStream_t stream) {
+                         unsigned long long *d_counts, unsigned long long *work_counter, hipStream_t stream) {
     FrameArgs a;
+    a.tail_counter = reinterpret_cast<unsigned *>(work_counter);
     const uint32_t spp = fd.spp;
     if (spp == 0 || spp > 64 || (spp & (spp - 1)))
         return fail(MR_ERR_INVALID, "mr_render_direct: spp must be a power of two <= 64 (got %u); use the batched pipeline", spp);

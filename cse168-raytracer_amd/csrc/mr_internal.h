@@ -157,16 +157,16 @@ mr_status launch_untile(const float *d_slots, float *d_image, uint32_t W, uint32
 
 // the fused direct-light frame (mr_frame.hip)
 mr_status launch_frame_b256(const DeviceScene &ds, const mr_frame_desc &fd, float *d_rgb, mr_hit *d_hits, mr_hit *d_shadow_hits,
-                            unsigned long long *d_counts, hipStream_t stream);
+                            unsigned long long *d_counts, unsigned long long *work_counter, hipStream_t stream);
 mr_status launch_frame_b128(const DeviceScene &ds, const mr_frame_desc &fd, float *d_rgb, mr_hit *d_hits, mr_hit *d_shadow_hits,
-                            unsigned long long *d_counts, hipStream_t stream);
+                            unsigned long long *d_counts, unsigned long long *work_counter, hipStream_t stream);
 // mr_frame.hip in its two workgroup sizes: frames of up to ~10 M samples (1080p at 4 spp) in 128-thread workgroups
 inline mr_status launch_frame(const DeviceScene &ds, const mr_frame_desc &fd, float *d_rgb, mr_hit *d_hits, mr_hit *d_shadow_hits,
-                              unsigned long long *d_counts, hipStream_t stream) {
+                              unsigned long long *d_counts, unsigned long long *work_counter, hipStream_t stream) {
     const unsigned long long rows = fd.band_world > 1 ? (fd.H + fd.band_world - 1) / fd.band_world : (fd.y1 > fd.y0 ? fd.y1 - fd.y0 : 0);
     const unsigned long long samples = rows * fd.W * fd.spp;
-    return samples <= 10000000ull ? launch_frame_b128(ds, fd, d_rgb, d_hits, d_shadow_hits, d_counts, stream)
-                                  : launch_frame_b256(ds, fd, d_rgb, d_hits, d_shadow_hits, d_counts, stream);
+    return samples <= 10000000ull ? launch_frame_b128(ds, fd, d_rgb, d_hits, d_shadow_hits, d_counts, work_counter, stream)
+                                  : launch_frame_b256(ds, fd, d_rgb, d_hits, d_shadow_hits, d_counts, work_counter, stream);
 }
 
 mr_status launch_shade_accumulate(const DeviceScene &ds, const mr_ray *d_rays, const mr_hit *d_hits, const float *d_weights,

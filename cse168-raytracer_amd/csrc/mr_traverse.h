@@ -38,13 +38,18 @@ constexpr unsigned long long kFrameLargeChunks = 1ull << 18;
 // (profiles/r02_xcd_runs.log; DESIGN.md section 4.14 for what the counters show).  Only for grids of kXcdMinGrid workgroups or more: a 1-spp frame is 8 100 workgroups,
 // little more than four per resident slot, and there the uneven cost of the regions shows as idle XCDs (-5 %).  Round 3: launches that
 // reach kFrameGridCapLarge workgroups (the fused frame kernel at 64 samples per pixel) take runs of kXcdRunLarge chunks.
-constexpr unsigned kXcdRun = 64, kXcdRunLarge = MIRO_RUN_LARGE, kXcdMinGrid = 16384;
-__device__ __forceinline__ unsigned xcd_block_id() {
-    const unsigned G = gridDim.x, b = blockIdx.x;
-    if (G < kXcdMinGrid) return b;
-    const unsigned run = G >= (unsigned)kFrameGridCapLarge ? kXcdRunLarge : kXcdRun;        // only the large-frame launch has that many workgroups
+#ifndef MIRO_XCD_MIN_GRID
+#define MIRO_XCD_MIN_GRID 16384
+#endif
+constexpr unsigned kXcdRun = 64, kXcdRunLarge = MIRO_RUN_LARGE, kXcdMinGrid = MIRO_XCD_MIN_GRID;
+__device__ __forceinline__ unsigned xcd_block_id_of(unsigned b, unsigned G, bool large, unsigned min_grid = kXcdMinGrid) {
+    if (G < min_grid) return b;
+    const unsigned run = large ? kXcdRunLarge : kXcdRun;
     const unsigned xcd = b & 7u, slot = b >> 3, grp = slot / run, k = slot - grp * run;
     return (grp + 1u) * (8u * run) <= G ? grp * (8u * run) + xcd * run + k : b;      // the ragged tail keeps the plain order
+}
+__device__ __forceinline__ unsigned xcd_block_id() {
+    return xcd_block_id_of(blockIdx.x, gridDim.x, gridDim.x >= (unsigned)kFrameGridCapLarge);   // only the large-frame launch has that many workgroups
 }
 constexpr float kEps = 1e-4f;        // Miro.h:9
 constexpr float kInf = __builtin_huge_valf();
