@@ -45,6 +45,11 @@ struct FrameArgs {
 // A kernel argument read where it is used, every time (volatile): the tail's parameters are needed a few dozen times per launch,
 // on a path 3 % of the workgroups take -- loaded once up front they would hold scalar registers through both traversals of
 // every workgroup (the kernel already keeps 70 of them spilled in VGPR lanes).
+// the longest run of chunks one reading of the tail counter hands out: a quarter of a body workgroup's share, 1 ... 8
+__device__ __forceinline__ unsigned tail_first_run(unsigned body_iters) {
+    const unsigned q = body_iters >> 2;
+    return q >= 8u ? 8u : q >= 4u ? 4u : q >= 2u ? 2u : 1u;
+}
 template <typename T>
 __device__ __forceinline__ T kernarg_now(size_t offset) {
     typedef const volatile T __attribute__((address_space(4))) *ptr_t;
@@ -62,8 +67,10 @@ __device__ __forceinline__ T kernarg_now(size_t offset) {
 // 98 % of the launch, 87 % after that, 4.3 % of the launch's workgroup-slots unused in all.  Shorter workgroups throughout cost
 // more than they return (profiles/r03_grid_ab.log).  A tail that whoever is free pulls from fills the drain and evens out the
 // XCDs (slots unused: 2.0 %), and with it LONGER body workgroups pay: 32 chunks each (15 228 workgroups instead of 65 536) is
-// +0.6 % over 8.  Bench frame 16.55 -> 16.85 Grays/s, 1080p x 16 spp 14.86 -> 15.28; 4 spp and below are better off without
-// (profiles/r03_tail_ab.log).  Every chunk is rendered by exactly one workgroup either way: the picture does not change.
+// +0.6 % over 8.  Bench frame 16.59 -> 16.93 Grays/s, 1080p x 16 spp 14.78 -> 15.26, BASELINE config 3 (bunny 1024^2 x 16) 41.0 ->
+// 48.4; the 20-bunny scene at 16 spp loses 2.7 % (its dear chunks sit at the bottom of the image, i.e. in the tail); 4 spp and
+// below are better off without (profiles/r03_tail_ab.log).  Every chunk is rendered by exactly one workgroup either way: the
+// picture does not change.
 #ifndef MIRO_TAIL_PERMILLE
 #define MIRO_TAIL_PERMILLE 60
 #endif
@@ -126,7 +133,8 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(7, 
 
     // body workgroups stride over their chunks as every trace kernel does; a tail workgroup (stride 0) asks the counter for its
     // next chunk instead -- values at or beyond tail_chunks mean "none left" (each tail workgroup reads exactly one such value)
-    __shared__ unsigned s_pull;
+    __shared__ unsigned s_pull, s_run[2];
+    if (tid == 0) { s_run[0] = 0; s_run[1] = 0; }     // (read back by thread 0 only)
     unsigned long long idx, stride, limit;
     if (blockIdx.x < a.body_wgs) {
         const unsigned long long body_end = (unsigned long long)a.body_wgs * a.body_iters * kTraceBlock;
@@ -138,11 +146,32 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(7, 
     }
     for (;; idx += stride) {
         if (__builtin_expect(stride == 0, 0)) {
-            if (tid == 0) s_pull = atomicAdd(kernarg_now<unsigned *>(offsetof(FrameArgs, tail_counter)), 1u);
+            // One reading of the counter hands out a RUN of consecutive chunks: a quarter of a body workgroup's share at a time (at
+            // most eight) for the first part of the tail, then half that, ... and one at a time for the rest (a chunk of background
+            // costs a few microseconds: a reading per chunk was 2 % of a frame that is mostly background; runs as long as a body
+            // workgroup's share bring the drain back).  s_run = {next chunk of the run, chunks left in it}.
+            if (tid == 0) {
+                unsigned left = s_run[1], next = s_run[0] + 1u;
+                if (left == 0) {
+                    const unsigned T = kernarg_now<uint32_t>(offsetof(FrameArgs, tail_chunks));
+                    unsigned k = atomicAdd(kernarg_now<unsigned *>(offsetof(FrameArgs, tail_counter)), 1u);
+                    s_pull = k;
+                    unsigned at = 0;
+                    next = 0xFFFFFFFFu;                // none left
+                    for (unsigned size = tail_first_run(kernarg_now<uint32_t>(offsetof(FrameArgs, body_iters))); size >= 1; size >>= 1) {
+                        const unsigned runs = size > 1 ? T / (4u * size) : T - at;      // a quarter of the tail per size; the rest one by one
+                        if (k < runs) { next = at + k * size; left = size; break; }
+                        k -= runs;
+                        at += runs * size;
+                    }
+                }
+                s_run[0] = next;
+                s_run[1] = next == 0xFFFFFFFFu ? 0u : left - 1u;
+            }
             __syncthreads();
-            const unsigned c = s_pull;
+            const unsigned c = s_run[0];
             __syncthreads();
-            if (c >= kernarg_now<uint32_t>(offsetof(FrameArgs, tail_chunks))) break;   // the whole workgroup leaves together: there are barriers on this path
+            if (c == 0xFFFFFFFFu) break;              // the whole workgroup leaves together: there are barriers on this path
             idx = ((unsigned long long)kernarg_now<uint32_t>(offsetof(FrameArgs, tail_base)) + c) * kTraceBlock + tid;
             if (idx >= limit) continue;               // waves beyond the end of a ragged last chunk
         } else if (idx >= limit) break;               // (whole waves: limit is a multiple of 64)
@@ -230,9 +259,16 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(7, 
     }
 
     if (stride == 0 && tid == 0) {                    // the tail's last reader re-arms the counter for the next launch
+        // every tail workgroup reads exactly one value at or beyond the number of runs
         const unsigned readers = gridDim.x - kernarg_now<uint32_t>(offsetof(FrameArgs, body_wgs));
-        if (s_pull == kernarg_now<uint32_t>(offsetof(FrameArgs, tail_chunks)) + readers - 1u)
-            atomicExch(kernarg_now<unsigned *>(offsetof(FrameArgs, tail_counter)), 0u);
+        const unsigned T = kernarg_now<uint32_t>(offsetof(FrameArgs, tail_chunks));
+        unsigned runs = 0, at = 0;
+        for (unsigned size = tail_first_run(kernarg_now<uint32_t>(offsetof(FrameArgs, body_iters))); size >= 1; size >>= 1) {
+            const unsigned r = size > 1 ? T / (4u * size) : T - at;
+            runs += r;
+            at += r * size;
+        }
+        if (s_pull == runs + readers - 1u) atomicExch(kernarg_now<unsigned *>(offsetof(FrameArgs, tail_counter)), 0u);
     }
     if (a.counts) {
         // rays traced.  Shadow rays: one atomic per workgroup (a single counter word drains ~88 atomics per microsecond:
