@@ -202,9 +202,12 @@ struct PhotonMapDev {
     // its root.  The cooperative search finds the blocks that touch the search sphere with these instead of walking planes.
     float4 *boxes = nullptr;
     int32_t layers = 0, layer_base[4] = {0, 0, 0, 0};
+    // hand-out counters of the estimate launches (mr_photon.hip): zero between launches, one per launch in flight
+    unsigned *work_counters = nullptr;
 };
+constexpr uint32_t kPhotonWorkCounters = 16;
 constexpr int kKnnMaxK = 512;     // nphotons limit of the wave-cooperative k-NN (PHOTON_SAMPLES = 500)
-mr_status launch_irradiance(const PhotonMapDev &pm, const float *d_pos, const float *d_normal, unsigned long long nq,
+mr_status launch_irradiance(const PhotonMapDev &pm, unsigned *work_counter, const float *d_pos, const float *d_normal, unsigned long long nq,
                             float max_dist, uint32_t k, float *d_irrad, int32_t *d_found, float *d_r2, unsigned long long *d_stats,
                             hipStream_t stream);
 constexpr int kPhotonStats = 12;  // see mr_photon_map_get_stats (miro_hip.h)

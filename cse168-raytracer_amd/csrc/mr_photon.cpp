@@ -54,6 +54,7 @@ struct mr_photon_map {
     bool balanced = false, on_device = false;
     PhotonMapDev dev;
     unsigned long long *d_stats = nullptr;   // work counters of the estimates (mr_photon_map_count_stats), else NULL
+    std::atomic<uint32_t> next_counter{0};   // which of dev.work_counters the next estimate launch takes
     uint32_t count() const { return (uint32_t)theta.size(); }
 };
 
@@ -120,7 +121,7 @@ struct Balancer {
 };
 
 void release(mr_photon_map *m) {
-    (void)hipFree(m->dev.rec); (void)hipFree(m->dev.power); (void)hipFree(m->dev.boxes); (void)hipFree(m->d_stats);
+    (void)hipFree(m->dev.rec); (void)hipFree(m->dev.power); (void)hipFree(m->dev.boxes); (void)hipFree(m->dev.work_counters); (void)hipFree(m->d_stats);
     m->dev = PhotonMapDev();
     m->d_stats = nullptr;
     m->on_device = false;
@@ -267,6 +268,10 @@ mr_status mr_photon_map_balance(mr_photon_map *m, uint32_t host_only) {
         MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->dev.boxes), boxes.size() * sizeof(float4)));
         MR_HIP_CHECK(hipMemcpy(m->dev.boxes, boxes.data(), boxes.size() * sizeof(float4), hipMemcpyHostToDevice));
     }
+    if (!m->dev.work_counters) {
+        MR_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->dev.work_counters), kPhotonWorkCounters * sizeof(unsigned)));
+        MR_HIP_CHECK(hipMemset(m->dev.work_counters, 0, kPhotonWorkCounters * sizeof(unsigned)));
+    }
     m->on_device = true;
     return MR_OK;
 }
@@ -302,7 +307,7 @@ mr_status mr_irradiance_estimate(mr_photon_map *m, const float *d_pos, const flo
     if (!d_pos || !d_normal || !d_irrad) return fail(MR_ERR_INVALID, "NULL argument");
     if (nphotons == 0 || nphotons > kKnnMaxK) return fail(MR_ERR_INVALID, "nphotons must be in [1, %d]", kKnnMaxK);
     MR_HIP_CHECK(hipSetDevice(m->device));
-    return launch_irradiance(m->dev, d_pos, d_normal, n_queries, max_dist, nphotons, d_irrad, d_found, d_r2, m->d_stats,
+    return launch_irradiance(m->dev, m->dev.work_counters + (m->next_counter.fetch_add(1) % kPhotonWorkCounters), d_pos, d_normal, n_queries, max_dist, nphotons, d_irrad, d_found, d_r2, m->d_stats,
                              static_cast<hipStream_t>(stream));
 }
 
@@ -355,7 +360,7 @@ mr_status mr_final_gather(mr_scene *s, mr_photon_map *global_map, mr_photon_map 
     if (st != MR_OK) return st;
     for (int i = 0; i < 2; i++) {
         if (!maps[i]) { d_irr[i] = nullptr; continue; }
-        st = launch_irradiance(maps[i]->dev, d_pos, d_nrm, n, max_dist, nphotons, d_irr[i], nullptr, nullptr, maps[i]->d_stats, stream);
+        st = launch_irradiance(maps[i]->dev, maps[i]->dev.work_counters + (maps[i]->next_counter.fetch_add(1) % kPhotonWorkCounters), d_pos, d_nrm, n, max_dist, nphotons, d_irr[i], nullptr, nullptr, maps[i]->d_stats, stream);
         if (st != MR_OK) return st;
     }
     return launch_gather_accumulate(d_irr[0], d_irr[1], n, spp, d_rgb, stream);

@@ -57,6 +57,14 @@ struct WaveLds {
 #ifndef MIRO_PHOTON_EXAMINE
 #define MIRO_PHOTON_EXAMINE 4
 #endif
+#ifndef MIRO_PHOTON_SMALL_BATCH
+#define MIRO_PHOTON_SMALL_BATCH 16
+#endif
+#ifndef MIRO_PHOTON_TAIL_QUERIES
+#define MIRO_PHOTON_TAIL_QUERIES 102400
+#endif
+constexpr unsigned kSmallBatch = MIRO_PHOTON_SMALL_BATCH;     // queries per batch at the end of a launch (see the kernel)
+constexpr unsigned long long kTailQueries = MIRO_PHOTON_TAIL_QUERIES;   // how many queries that end is: 1.25 small batches per resident wave
 constexpr int kExamine = MIRO_PHOTON_EXAMINE;   // listed blocks examined per step (their loads are in flight together)
 constexpr int kList = 128;         // an expansion adds up to 64 entries and runs only while at most kList - 64 are waiting
 __host__ __device__ inline int wave_lds_words(int stack_cap) { return 2 * kCap + 256 + stack_cap + 2 * kList; }
@@ -230,12 +238,11 @@ __device__ __forceinline__ int first_overflow(const PhotonMapDev &pm, float qx, 
 template <bool STATS>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(STATS ? 4 : 5, 8))) void irradiance_kernel(PhotonMapDev pm, const float *qpos, const float *qnrm,
                                                             unsigned long long nq, float max_dist, int k, float *irrad,
-                                                            int *found_out, float *r2_out, unsigned long long *stats, int stack_cap) {
+                                                            int *found_out, float *r2_out, unsigned long long *stats, int stack_cap,
+                                                            unsigned *work_counter) {
     extern __shared__ int s_lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const WaveLds w = wave_lds(s_lds + wv * wave_lds_words(stack_cap), stack_cap);
-    const unsigned long long wave_id = (unsigned long long)blockIdx.x * kWaves + wv;
-    const unsigned long long n_waves = (unsigned long long)gridDim.x * kWaves;
     // node of this lane inside a block: level lv (0..5), offset within the level
     const int lv = 31 - __clz(lane + 1);
     const int off_in_level = lane + 1 - (1 << lv);
@@ -244,15 +251,30 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(STATS ? 
     const float md2 = max_dist * max_dist;
     unsigned long long st_queries = 0, st_blocks = 0, st_records = 0, st_tighten = 0, st_prepass = 0, st_retries = 0;
     unsigned long long st_reached = 0, st_cands = 0, st_top = 0, st_mid = 0, st_unguessed = 0;
-    // a wave takes 64 consecutive queries at a time: first every lane finds its own query's m* (first_overflow), then
-    // the wave searches the 64 queries one after the other
-    for (unsigned long long base = wave_id * 64ull; base < nq; base += n_waves * 64ull) {
+    // A wave takes a BATCH of consecutive queries at a time: first every lane finds its own query's m* (first_overflow), then
+    // the wave searches the batch's queries one after the other.  Batches are handed out by a counter (one atomic per batch, no
+    // barrier: waves share nothing): 64 queries each, and kSmallBatch each for the last kTailQueries of the launch.  Dealt out
+    // statically -- batch b to wave b mod (waves of the grid) -- a wave got one or two batches of 3.7 ms each in a 23.5 ms launch
+    // (config 5: 32 400 batches over 20 480 waves, 5 120 resident) and the launch drained for the length of a batch.  Batches of 64
+    // from the counter: 23.2 -> 22.8 ms; the last 5 % in batches of 16: 22.15 ms (smaller or more of them cost more than they
+    // return: the pre-pass of a batch of 8 runs on 8 lanes; profiles/r03_photon_batches.log).  The counter is zero before the
+    // launch; the wave that reads the last value re-arms it.
+    const unsigned long long n_big = (nq > kTailQueries ? nq - kTailQueries : 0ull) / 64ull;   // batches of 64
+    const unsigned long long n_small = (nq - 64ull * n_big + kSmallBatch - 1) / kSmallBatch;  // batches of kSmallBatch (the last one ragged)
+    unsigned pulled = 0;
+    for (;;) {
+      if (lane == 0) pulled = atomicAdd(work_counter, 1u);
+      pulled = (unsigned)__builtin_amdgcn_readfirstlane((int)pulled);
+      if (pulled >= n_big + n_small) break;
+      const unsigned long long base = pulled < n_big ? 64ull * pulled : 64ull * n_big + (unsigned long long)kSmallBatch * (pulled - n_big);
+      const unsigned long long bend0 = base + (pulled < n_big ? 64ull : (unsigned long long)kSmallBatch);
+      const unsigned long long bend = bend0 < nq ? bend0 : nq;                                 // end of this batch
       int my_mstar = 0;
       float my_radius = md2;
       {
           const unsigned long long qa = base + (unsigned)lane;
           unsigned visits = 0;
-          if (qa < nq) {
+          if (qa < bend) {
               const float ax = qnrm[3 * qa];
               if (ax == ax)
                   my_mstar = first_overflow(pm, qpos[3 * qa], qpos[3 * qa + 1], qpos[3 * qa + 2], ax, qnrm[3 * qa + 1], qnrm[3 * qa + 2], md2, k,
@@ -264,10 +286,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(STATS ? 
           }
       }
 #ifdef MIRO_PHOTON_PREPASS_ONLY      /* timing probe: the reference-order pre-pass alone (results are NOT the estimate) */
-      if (base + (unsigned)lane < nq) { irrad[3 * (base + lane)] = my_radius; if (found_out) found_out[base + lane] = my_mstar; }
+      if (base + (unsigned)lane < bend) { irrad[3 * (base + lane)] = my_radius; if (found_out) found_out[base + lane] = my_mstar; }
       continue;
 #endif
-      const int n_here = nq - base < 64ull ? (int)(nq - base) : 64;
+      const int n_here = (int)(bend - base);
       // The previous query of this wave (the neighbouring pixel) and its final radius: a GUESS for this one's.  If both
       // queries saw the same candidates the k-th nearest of this one would lie within sqrt(prev) + |q - q_prev| (triangle
       // inequality); they need not (the facing test depends on the normal, m* differs), so the guess is verified: a search
@@ -439,6 +461,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(STATS ? 
         }
       }
     }
+    // every wave of the grid reads exactly one value at or beyond the number of batches: the last of them re-arms the counter
+    if (lane == 0 && pulled == (unsigned)(n_big + n_small) + gridDim.x * kWaves - 1u) atomicExch(work_counter, 0u);
     if (STATS && lane == 0 && stats) {
         atomicAdd(&stats[0], st_queries); atomicAdd(&stats[1], st_blocks); atomicAdd(&stats[2], st_records);
         atomicAdd(&stats[3], st_tighten); atomicAdd(&stats[4], st_prepass); atomicAdd(&stats[5], st_retries);
@@ -449,7 +473,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(STATS ? 
 
 }  // namespace
 
-mr_status launch_irradiance(const PhotonMapDev &pm, const float *d_pos, const float *d_normal, unsigned long long nq,
+mr_status launch_irradiance(const PhotonMapDev &pm, unsigned *work_counter, const float *d_pos, const float *d_normal, unsigned long long nq,
                             float max_dist, uint32_t k, float *d_irrad, int32_t *d_found, float *d_r2, unsigned long long *d_stats,
                             hipStream_t stream) {
     static_assert(kTighten + 64 <= kCap && kKnnMaxK <= kTighten, "candidate buffer must hold k plus one block");
@@ -460,14 +484,17 @@ mr_status launch_irradiance(const PhotonMapDev &pm, const float *d_pos, const fl
     while (layers < 4 && (1ll << (6 * layers)) <= (long long)pm.n) layers++;
     const int stack_cap = layers > 2 ? 64 * (layers - 2) : 64;      // only blocks that have blocks below them wait on the stack
     const size_t lds = (size_t)kWaves * wave_lds_words(stack_cap) * sizeof(int);
+    if (!work_counter) return fail(MR_ERR_STATE, "photon map without hand-out counters (not uploaded?)");
+    if (nq >= (1ull << 31)) return fail(MR_ERR_INVALID, "at most 2^31 - 1 queries per estimate launch");
+    // every resident slot gets a workgroup (five per CU, a few more in case fewer registers are taken): they pull their batches
     unsigned long long blocks = (nq + kWaves - 1) / kWaves;
-    if (blocks > 256ull * 20ull) blocks = 256ull * 20ull;
+    if (blocks > 256ull * 6ull) blocks = 256ull * 6ull;
     if (d_stats)
         hipLaunchKernelGGL(irradiance_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), lds, stream, pm, d_pos, d_normal, nq, max_dist,
-                           (int)k, d_irrad, d_found, d_r2, d_stats, stack_cap);
+                           (int)k, d_irrad, d_found, d_r2, d_stats, stack_cap, work_counter);
     else
         hipLaunchKernelGGL(irradiance_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds, stream, pm, d_pos, d_normal, nq, max_dist,
-                           (int)k, d_irrad, d_found, d_r2, d_stats, stack_cap);
+                           (int)k, d_irrad, d_found, d_r2, d_stats, stack_cap, work_counter);
     MR_HIP_CHECK(hipGetLastError());
     return MR_OK;
 }
