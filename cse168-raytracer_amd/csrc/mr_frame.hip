@@ -58,7 +58,7 @@ __device__ __forceinline__ T kernarg_now(size_t offset) {
 }
 
 // The launch's shape.  Workgroups b < body_wgs render chunks b', b' + body_wgs, ... (body_iters of them, b' = the XCD-aware
-// permutation of b).  Frames of 2^16 chunks or more (1080p from 16 samples per pixel) keep their last tail_chunks chunks -- 6 % --
+// permutation of b).  Frames of 60 000 chunks or more (1080p from 8 samples per pixel; 46 080 chunks: -4 %) keep their last tail_chunks chunks -- 6 % --
 // out of that: kTailWgs further workgroups, the last to be dealt out, one per resident slot, PULL them one at a time from a
 // counter until none is left.  Why (tools/wg_timeline.py, profiles/r03_wg_timeline.log): workgroups are dealt out in index order,
 // seven per CU, every eighth to the same XCD whatever that XCD still has to do.  With 65 536 equal workgroups (8 chunks, 0.42 ms
@@ -78,7 +78,7 @@ __device__ __forceinline__ T kernarg_now(size_t offset) {
 #define MIRO_BODY_ITERS 32
 #endif
 #ifndef MIRO_TAIL_MIN_CHUNKS
-#define MIRO_TAIL_MIN_CHUNKS (1ull << 16)
+#define MIRO_TAIL_MIN_CHUNKS 60000ull     /* 1080p x 8 spp, and an eighth of the bench frame (one of 8 ranks), are 64 800 */
 #endif
 constexpr uint32_t kTailWgs = 1792 * (256 / kTraceBlock);   // one per resident slot: 7 workgroups of 4 waves x 256 CUs
 constexpr uint32_t kBodyMinWgs = 14000;      // ~8 body workgroups per resident slot, at least

@@ -159,16 +159,16 @@ def test_fused_frame_full_size_properties(miro, spp):
 
 
 @pytest.mark.parametrize("W,H,spp", [(1024, 1024, 64), (1023, 1031, 64), (1400, 1500, 64), (1024, 1024, 16), (1021, 1027, 16),
-                                     (1920, 1080, 16), (2048, 1100, 8)])
+                                     (1920, 1080, 16), (2048, 1100, 8), (1920, 135, 64), (1000, 961, 16)])
 def test_large_frame_schedule_renders_every_chunk_once(miro, W, H, spp):
-    """Frames of 2^16 chunks or more are launched with the schedule of frame_schedule() (mr_frame.hip): body workgroups striding
+    """Frames of 60 000 chunks or more are launched with the schedule of frame_schedule() (mr_frame.hip): body workgroups striding
     over their chunks, and a tail that the last workgroups pull chunk by chunk from a counter (re-armed by its last reader: the
     frame is rendered three times here).  The picture is the one narrow windows give -- those are below the threshold and take
     the plain strided schedule.  Sizes: the threshold exactly, ragged last chunks, 8 / 16 / 32 chunks per body workgroup."""
     name = "bunny"
     d = scenes.SCENES[name]
     sc = product_scene(miro, name)
-    assert (W * H * spp + 255) // 256 >= 1 << 16
+    assert (W * H * spp + 255) // 256 >= 60000
     full = mframe.FusedFrame(sc, d, W, H, spp=spp, jitter=True, seed=3, tiled=False)
     for _ in range(3):
         full.d_rgb.fill_(-1.0)
@@ -176,10 +176,10 @@ def test_large_frame_schedule_renders_every_chunk_once(miro, W, H, spp):
     n_p, n_s = full.ray_counts(steps=3)
     assert n_p == W * H * spp
     parts = []
-    rows = max(1, (256 * ((1 << 16) - 1)) // (W * spp))       # the tallest window below the threshold
+    rows = max(1, (256 * 59999) // (W * spp))                 # the tallest window below the threshold
     for y0 in range(0, H, rows):
         y1 = min(H, y0 + rows)
-        assert ((y1 - y0) * W * spp + 255) // 256 < 1 << 16
+        assert ((y1 - y0) * W * spp + 255) // 256 < 60000
         rgb = torch.full(((y1 - y0) * W, 3), -2.0, dtype=torch.float32, device="cuda")
         sc.render_direct(full.cam, W, H, rgb, d["light"], d["wattage"], y0=y0, y1=y1, spp=spp, jitter=True, seed=3, tiled=False)
         parts.append(rgb)
