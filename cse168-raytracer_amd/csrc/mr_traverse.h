@@ -22,7 +22,10 @@ constexpr int kBlock = 256;          // 4 waves per workgroup
 #define MIRO_TRACE_BLOCK 256
 #endif
 constexpr int kTraceBlock = MIRO_TRACE_BLOCK;   // threads per workgroup of the trace kernels (their LDS stack is [depth][kTraceBlock])
-constexpr int kTraceGridCap = 32768; // workgroups per trace launch (see launch_trace_t)
+#ifndef MIRO_GRID_CAP
+#define MIRO_GRID_CAP 32768
+#endif
+constexpr int kTraceGridCap = MIRO_GRID_CAP; // workgroups per trace launch (see launch_trace_t)
 // the fused frame kernel on frames of 2^18 chunks or more (1080p at 64 spp is 518 400): twice the workgroups, and XCD runs of 256
 // chunks instead of 64 -- +1.1 % there, while frames of 4 to 16 samples per pixel lose 1.5-4 % to either (profiles/r03_grid_ab.log)
 #ifndef MIRO_CAP_LARGE
