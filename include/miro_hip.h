@@ -282,7 +282,11 @@ typedef struct mr_frame_desc {
 } mr_frame_desc;
 /* d_rgb: rows*W*3 floats (window rows in band order).  Optional device outputs (NULL to skip): d_hits / d_shadow_hits,
  * rows*W*spp records each -- the shadow record of a sample whose primary ray missed is {t = 0, prim = MR_MISS};
- * d_counts[2]: += primary rays, += shadow rays traced (not zeroed by the call). */
+ * d_counts[2]: += primary rays, += shadow rays traced (not zeroed by the call).
+ * Streams: a frame of 60 000 chunks of 256 samples or more hands the last 6 % of its chunks out through one of 64 per-scene
+ * device counters (taken round-robin per call, re-armed by the launch itself, so a captured HIP graph replays): calls on one
+ * scene may overlap on different streams, up to 64 at a time; a captured graph keeps its counter -- do not replay it while
+ * other frames of the same scene are in flight on other streams. */
 mr_status mr_render_direct(mr_scene *scene, const mr_frame_desc *frame, float *d_rgb, mr_hit *d_hits, mr_hit *d_shadow_hits,
                            uint64_t *d_counts, void *stream);
 
