@@ -81,7 +81,10 @@ __device__ __forceinline__ T kernarg_now(size_t offset) {
 #define MIRO_TAIL_MIN_CHUNKS 60000ull     /* 1080p x 8 spp, and an eighth of the bench frame (one of 8 ranks), are 64 800 */
 #endif
 constexpr uint32_t kTailWgs = 1792 * (256 / kTraceBlock);   // one per resident slot: 7 workgroups of 4 waves x 256 CUs
-constexpr uint32_t kBodyMinWgs = 14000;      // ~8 body workgroups per resident slot, at least
+#ifndef MIRO_BODY_MIN_WGS
+#define MIRO_BODY_MIN_WGS 14000
+#endif
+constexpr uint32_t kBodyMinWgs = MIRO_BODY_MIN_WGS;      // ~8 body workgroups per resident slot, at least
 struct FrameShape { uint32_t body_wgs, body_iters, tail_chunks, grid; };
 inline FrameShape frame_schedule(unsigned long long chunks) {
     FrameShape s;
