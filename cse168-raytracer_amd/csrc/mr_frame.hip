@@ -120,7 +120,10 @@ inline FrameShape frame_schedule(unsigned long long chunks) {
 __device__ unsigned long long g_wg_times[4 * 131072];
 #endif
 template <int VAR, int SHADOW, bool MAT>
-__global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(7, 8))) void frame_kernel(FrameArgs a) {
+#ifndef MIRO_FRAME_WAVES
+#define MIRO_FRAME_WAVES 7      /* 72 registers; 6 (80 registers, nothing spilled to scratch) is 6.5 % slower on the bench frame: profiles/r03_tail_ab.log */
+#endif
+__global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(MIRO_FRAME_WAVES, 8))) void frame_kernel(FrameArgs a) {
 #if defined(MIRO_WG_TIMES) && MIRO_TRACE_BLOCK == 256
     const unsigned long long wg_t0 = wall_clock64();
 #endif
