@@ -42,14 +42,14 @@ struct FrameArgs {
     unsigned *tail_counter;      // hand-out counter of the tail chunks: 0 before the launch, left at 0 by its last reader
 };
 
-// A kernel argument read where it is used, every time (volatile): the tail's parameters are needed a few dozen times per launch,
-// on a path 3 % of the workgroups take -- loaded once up front they would hold scalar registers through both traversals of
-// every workgroup (the kernel already keeps 70 of them spilled in VGPR lanes).
 // the longest run of chunks one reading of the tail counter hands out: a quarter of a body workgroup's share, 1 ... 8
 __device__ __forceinline__ unsigned tail_first_run(unsigned body_iters) {
     const unsigned q = body_iters >> 2;
     return q >= 8u ? 8u : q >= 4u ? 4u : q >= 2u ? 2u : 1u;
 }
+// A kernel argument read where it is used, every time (volatile): the tail's parameters are needed a few dozen times per launch,
+// on a path a tenth of the workgroups take -- loaded once up front they would hold scalar registers through both traversals of
+// every workgroup (the kernel already keeps 50 of them spilled in VGPR lanes; a first version that kept them lost 0.9 %).
 template <typename T>
 __device__ __forceinline__ T kernarg_now(size_t offset) {
     typedef const volatile T __attribute__((address_space(4))) *ptr_t;
@@ -59,7 +59,7 @@ __device__ __forceinline__ T kernarg_now(size_t offset) {
 
 // The launch's shape.  Workgroups b < body_wgs render chunks b', b' + body_wgs, ... (body_iters of them, b' = the XCD-aware
 // permutation of b).  Frames of 60 000 chunks or more (1080p from 8 samples per pixel; 46 080 chunks: -4 %) keep their last tail_chunks chunks -- 6 % --
-// out of that: kTailWgs further workgroups, the last to be dealt out, one per resident slot, PULL them one at a time from a
+// out of that: kTailWgs further workgroups, the last to be dealt out, one per resident slot, PULL them in short runs from a
 // counter until none is left.  Why (tools/wg_timeline.py, profiles/r03_wg_timeline.log): workgroups are dealt out in index order,
 // seven per CU, every eighth to the same XCD whatever that XCD still has to do.  With 65 536 equal workgroups (8 chunks, 0.42 ms
 // each on the bench frame) the last ones started at 97 % of the launch and the CUs drained for a whole workgroup lifetime, while
