@@ -99,6 +99,27 @@ def test_fused_frame_of_one_ranks_bands(miro, world, band):
     assert tuple(tot) == whole.ray_counts()
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_frame_shares_of_the_ranks_are_the_unsharded_frame(miro, world):
+    """The bench frame (sponza 1920x1080, 64 samples per pixel) as bench.py shards it -- interleaved bands of 8 rows -- rendered
+    share by share on one device: each share is a large launch of its own (a half: 259 200 chunks, an eighth: 64 800 -- both take
+    the schedule with the pulled tail, mr_frame.hip), and together they are the unsharded frame byte for byte."""
+    name, W, H, spp, band = "sponza", 1920, 1080, 64, 8
+    sc = product_scene(miro, name)
+    whole = mframe.FusedFrame(sc, name, W, H, spp=spp)
+    whole.step()
+    full = torch.full((H, W, 3), -1.0, dtype=torch.float32, device="cuda")
+    for r in range(world):
+        fu = mframe.FusedFrame(sc, name, W, H, spp=spp, band=band, rank=r, world=world)
+        assert fu.n >= 60000 * 256
+        fu.step()
+        rows = torch.from_numpy(mframe.rows_of(mframe.band_rows(H, band, r, world))).to("cuda")
+        full[rows] = fu.d_rgb.view(len(rows), W, 3)
+        del fu
+    torch.cuda.synchronize()
+    assert torch.equal(full.view(-1, 3).view(torch.int32), whole.d_rgb.view(torch.int32))
+
+
 @pytest.mark.parametrize("world,band", [(2, 6), (4, 5)])
 def test_fused_hit_records_of_the_ranks_deinterleave_to_the_unsharded_buffer(miro, world, band):
     """The hit-buffer parity mode of SURVEY section 8e on the fused path: every rank's primary mr_hit records (image order
