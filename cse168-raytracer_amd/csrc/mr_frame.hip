@@ -84,6 +84,10 @@ constexpr uint32_t kTailWgs = 1792 * (256 / kTraceBlock);   // one per resident 
 #ifndef MIRO_BODY_MIN_WGS
 #define MIRO_BODY_MIN_WGS 14000
 #endif
+#ifndef MIRO_TAIL_PERMILLE_MID
+#define MIRO_TAIL_PERMILLE_MID 60
+#define MIRO_BODY_MIN_WGS_MID 14000
+#endif
 constexpr uint32_t kBodyMinWgs = MIRO_BODY_MIN_WGS;      // ~8 body workgroups per resident slot, at least
 struct FrameShape { uint32_t body_wgs, body_iters, tail_chunks, grid; };
 inline FrameShape frame_schedule(unsigned long long chunks) {
@@ -96,9 +100,10 @@ inline FrameShape frame_schedule(unsigned long long chunks) {
         s.grid = s.body_wgs;
         return s;
     }
-    const unsigned long long tail_target = chunks * MIRO_TAIL_PERMILLE / 1000;
+    const bool mid = chunks < kFrameLargeChunks;      // below 2^18 chunks a launch is a few milliseconds: shorter shares, more tail
+    const unsigned long long tail_target = chunks * (mid ? MIRO_TAIL_PERMILLE_MID : MIRO_TAIL_PERMILLE) / 1000;
     uint32_t m = MIRO_BODY_ITERS;
-    while (m > 1 && (chunks - tail_target) / m < kBodyMinWgs) m >>= 1;
+    while (m > 1 && (chunks - tail_target) / m < (mid ? (uint32_t)MIRO_BODY_MIN_WGS_MID : kBodyMinWgs)) m >>= 1;
     while ((unsigned long long)m * (unsigned long long)kFrameGridCapLarge < chunks) m <<= 1;
     s.body_iters = m;
     s.body_wgs = (uint32_t)((chunks - tail_target) / m);
